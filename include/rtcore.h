@@ -1,0 +1,235 @@
+/*
+ * rtcore.h — C-ABI of the MI355X render core (librtcore.so).
+ *
+ * Drop-in boundary for the per-pixel hot path of karolzwolak/raytracer:
+ * the reference's pixel loop `image.set_each_pixel(|x,y| self.color_at_pixel(x,y), pb)`
+ * (src/render/renderer.rs:71 and :95, src/render/image.rs:66-82) is replaced by one call that
+ * fills the f64 RGB pixel array.  The reference has no FFI of its own (pure Rust); every entry point
+ * below names the reference interface it replaces.  The Rust-side binding is shown in INTEGRATION.md.
+ *
+ * Conventions: every real is IEEE f64; Point/Vector/Color are 3 x f64;
+ * a Matrix is 16 x f64 row-major exactly as src/math/matrix.rs:8-10,266-270 stores it.
+ * All arrays are borrowed for the duration of the call that receives them.
+ * Every function returns 0 on success and a negative rt_status otherwise; rt_last_error()
+ * gives a thread-local message.  Nothing unwinds or aborts across this boundary.
+ */
+#ifndef RTCORE_H
+#define RTCORE_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RT_ABI_VERSION 1u
+
+/* ---- child references --------------------------------------------------------------------- */
+/* A child reference packs the kind of an `Object` (src/scene/object.rs:26-30) in bits 31..30   */
+/* and the index into the matching table in bits 29..0.                                         */
+#define RT_REF_KIND_SHIFT 30u
+#define RT_REF_INDEX_MASK 0x3FFFFFFFu
+#define RT_REF_NODE 0u /* ObjectKind::Group  -> index into the node tables  */
+#define RT_REF_PRIM 1u /* ObjectKind::Primitive -> index into the prim tables */
+#define RT_REF_CSG  2u /* ObjectKind::Csg    -> index into the csg tables   */
+#define RT_MAKE_REF(kind, index) (((uint32_t)(kind) << RT_REF_KIND_SHIFT) | ((uint32_t)(index) & RT_REF_INDEX_MASK))
+#define RT_NONE 0xFFFFFFFFu
+
+/* ---- shape tags: src/scene/object/primitive/shape.rs:15-32 --------------------------------- */
+enum rt_shape {
+  RT_SHAPE_SPHERE = 0,
+  RT_SHAPE_PLANE = 1,
+  RT_SHAPE_CUBE = 2,
+  RT_SHAPE_CYLINDER = 3,
+  RT_SHAPE_CONE = 4,
+  RT_SHAPE_TRIANGLE = 5,
+  RT_SHAPE_SMOOTH_TRIANGLE = 6,
+  RT_SHAPE_BBOX = 7 /* behaves as a cube (shape.rs:48,60) */
+};
+
+/* ---- pattern tags: src/scene/object/material/pattern.rs:7-37 ------------------------------- */
+enum rt_pattern {
+  RT_PATTERN_CONST = 0,
+  RT_PATTERN_STRIPE = 1,
+  RT_PATTERN_GRADIENT = 2, /* c1 = c_start, c2 = c_dist (= end - start), pattern.rs:48-54 */
+  RT_PATTERN_RING = 3,
+  RT_PATTERN_CHECKERS = 4,
+  RT_PATTERN_TEST = 5
+};
+
+/* ---- CSG operations: src/scene/object/csg.rs:29-34 ----------------------------------------- */
+enum rt_csg_op { RT_CSG_UNION = 0, RT_CSG_INTERSECTION = 1, RT_CSG_DIFFERENCE = 2 };
+
+enum rt_status {
+  RT_OK = 0,
+  RT_ERR_INVALID_ARGUMENT = -1, /* NULL where data is required, inconsistent counts, bad refs   */
+  RT_ERR_UNSUPPORTED = -2,      /* scene exceeds a documented device limit      */
+  RT_ERR_DEVICE = -3,           /* a HIP call failed, or no gfx950 device is usable             */
+  RT_ERR_OVERFLOW = -4          /* a per-ray bounded list overflowed while rendering            */
+};
+
+/* Material scalars, in the order of `struct Material` (src/scene/object/material.rs:10-20). */
+#define RT_MAT_AMBIENT 0
+#define RT_MAT_DIFFUSE 1
+#define RT_MAT_SPECULAR 2
+#define RT_MAT_SHININESS 3
+#define RT_MAT_REFLECTIVITY 4
+#define RT_MAT_TRANSPARENCY 5
+#define RT_MAT_REFRACTIVE_INDEX 6
+#define RT_MAT_STRIDE 8 /* [7] is padding and must be 0 */
+
+/*
+ * The flattened, immutable scene: what `Scene::objects()` / `Scene::light_sources()`
+ * (src/scene.rs:22-28) hold after `Scene::compute_bvh()` (src/scene.rs:38), written out as tables.
+ *
+ * Nodes mirror `ObjectGroup` (src/scene/object/group.rs:16-20): node i owns the child references
+ * child_ref[node_child_begin[i] .. node_child_begin[i+1]) IN THE ORDER of `ObjectGroup::children`
+ * (traversal order decides ties, group.rs:171-201) and the group's own bounding box.
+ * Node 0 is the scene root (`Scene::objects`).
+ */
+typedef struct rt_scene_desc {
+  uint32_t abi_version; /* RT_ABI_VERSION */
+
+  /* groups */
+  uint32_t n_nodes;
+  const double* node_bbox;          /* [n_nodes][6]  min x,y,z then max x,y,z (bounding_box.rs:25-28) */
+  const uint32_t* node_child_begin; /* [n_nodes + 1] */
+  uint32_t n_child_refs;
+  const uint32_t* child_ref;        /* [n_child_refs] RT_MAKE_REF(kind, index) */
+
+  /* primitives: `PrimitiveObject` (object.rs:357-363). The index IS the object identity that the
+   * refractive-index container walk compares (intersection.rs:145-153,280-287). */
+  uint32_t n_prims;
+  const uint8_t* prim_shape;     /* [n_prims] enum rt_shape */
+  const uint32_t* prim_material; /* [n_prims] index into the material tables */
+  const uint32_t* prim_xform;    /* [n_prims] index into xform_inv, RT_NONE when transformation_inverse is None */
+  const uint32_t* prim_geom;     /* [n_prims] triangle index (shapes 5,6), quadric index (shapes 3,4), else RT_NONE */
+  const uint32_t* prim_csg_left; /* [n_prims] bit d set <=> `csg.left.includes(prim)` (csg.rs:93, object.rs:98-104)
+                                    for the enclosing CSG object whose nesting depth is d (outermost = 0); 0 outside CSG */
+
+  uint32_t n_xforms;
+  const double* xform_inv; /* [n_xforms][16] `transformation_inverse` exactly as the reference holds it */
+
+  /* triangles: Triangle (triangle.rs:10-17) and SmoothTriangle (smooth_triangle.rs:13-22), world space */
+  uint32_t n_tris;
+  const double* tri_p1; /* [n_tris][3] */
+  const double* tri_e1; /* [n_tris][3] p2 - p1 */
+  const double* tri_e2; /* [n_tris][3] p3 - p1 */
+  const double* tri_n1; /* [n_tris][3] smooth: n1;  flat: the precomputed unit normal */
+  const double* tri_n2; /* [n_tris][3] smooth: n2;  flat: unused (0) */
+  const double* tri_n3; /* [n_tris][3] smooth: n3;  flat: unused (0) */
+
+  /* cylinders and cones: cylinder.rs:14-18, cone.rs:13-17 */
+  uint32_t n_quadrics;
+  const double* quadric_y_min;   /* [n_quadrics] may be -inf */
+  const double* quadric_y_max;   /* [n_quadrics] may be +inf */
+  const uint8_t* quadric_closed; /* [n_quadrics] 0/1 */
+
+  /* CSG objects: csg.rs:68-74 */
+  uint32_t n_csgs;
+  const uint8_t* csg_op;      /* [n_csgs] enum rt_csg_op */
+  const uint32_t* csg_left;   /* [n_csgs] child reference */
+  const uint32_t* csg_right;  /* [n_csgs] child reference */
+  const uint8_t* csg_depth;   /* [n_csgs] CSG nesting depth of this object (outermost = 0), < 32 */
+
+  /* materials: material.rs:10-20 + pattern.rs:7-37 */
+  uint32_t n_materials;
+  const double* material;       /* [n_materials][RT_MAT_STRIDE] */
+  const uint8_t* pattern_kind;  /* [n_materials] enum rt_pattern */
+  const double* pattern_c1;     /* [n_materials][3] */
+  const double* pattern_c2;     /* [n_materials][3] */
+  const double* pattern_inv;    /* [n_materials][16] inverse pattern transform (identity for CONST) */
+
+  /* lights: point_light.rs:7-10 */
+  uint32_t n_lights;
+  const double* light_pos;       /* [n_lights][3] */
+  const double* light_intensity; /* [n_lights][3] */
+} rt_scene_desc;
+
+/* `Camera` (src/scene/camera.rs:9-18); the three derived scalars are computed by the caller exactly
+ * as camera.rs:166-175 does (they are private fields there). */
+typedef struct rt_camera {
+  uint32_t width, height;
+  double inv_view[16];
+  double half_width, half_height, pixel_size;
+} rt_camera;
+
+/* `Renderer::supersampling_offsets` (renderer.rs:24,40-48), `Integrator::max_recursive_depth` and
+ * `Integrator::use_shadow_intensity` (integrator.rs:19-32). */
+typedef struct rt_options {
+  uint32_t n_offsets;        /* 1..5 */
+  double offsets[5];
+  uint32_t max_depth;        /* max_recursive_depth; device limit RT_MAX_DEPTH */
+  uint32_t shadow_intensity; /* 1: production (intensity sums); 0: boolean shadows of the unit tests */
+} rt_options;
+
+#define RT_MAX_DEPTH 16u
+
+/* Per-render ray statistics (unique rays: each reflect/refract subtree is traced once per hit). */
+typedef struct rt_stats {
+  uint64_t rays_primary, rays_shadow, rays_reflect, rays_refract;
+  uint64_t node_visits, tri_tests, prim_tests;
+  uint64_t overflow_pixels;
+  double ms_upload, ms_kernel, ms_download;
+} rt_stats;
+
+/* ---- library ------------------------------------------------------------------------------ */
+uint32_t rt_abi_version(void);
+const char* rt_last_error(void); /* thread-local, static storage */
+int rt_device_count(void);       /* number of usable gfx950 devices, <0 on error */
+
+/* ---- one-shot render: replaces Image::set_each_pixel(|x,y| color_at_pixel(x,y))
+ *      at renderer.rs:71,95 / image.rs:66-82.
+ * out_rgb: caller-owned HOST buffer, width*height*3 f64, row-major (id = y*width + x, image.rs:78-79),
+ * channels r,g,b.  Uploads the scene to the current HIP device, renders, copies back. */
+int rt_render(const rt_scene_desc* scene, const rt_camera* camera, const rt_options* options,
+              double* out_rgb, rt_stats* stats /* nullable */);
+
+/* ---- resident-scene API (what an animation loop or a multi-GPU driver uses) ----------------- */
+typedef struct rt_scene rt_scene; /* opaque: the scene re-laid-out in device memory */
+
+/* Validates the tables, builds the device layout and uploads it to the current HIP device.
+ * Replaces nothing in the reference (there the scene is already in host memory); it is the
+ * "hand a flattened scene to the kernels" step of the north star. */
+int rt_scene_create(const rt_scene_desc* scene, rt_scene** out);
+void rt_scene_destroy(rt_scene* scene);
+
+/* Tile partition for multi-GPU frames: the image is cut into 8x8-pixel tiles in
+ * row-major tile order; part p of n_parts owns the tiles with tile_id % n_parts == p.  The output
+ * is PACKED: the k-th owned tile occupies d_out_rgb[k*64*3 .. (k+1)*64*3), pixel (tx,ty) of the tile
+ * at offset (ty*8+tx)*3.  rt_tile_count() gives the number of owned tiles.  With n_parts == 1 use
+ * rt_render_device() to get the plain row-major image instead. */
+#define RT_TILE_DIM 8u
+uint32_t rt_tile_count(uint32_t width, uint32_t height, uint32_t part, uint32_t n_parts);
+
+/* Renders part `part` of `n_parts` into DEVICE memory on `hip_stream` (a hipStream_t, may be NULL).
+ * Asynchronous with respect to the host unless stats != NULL (then it synchronises the stream to read
+ * the counters).  Same per-pixel semantics as rt_render: Renderer::color_at_pixel (renderer.rs:50-66). */
+int rt_render_tiles_device(const rt_scene* scene, const rt_camera* camera, const rt_options* options,
+                           uint32_t part, uint32_t n_parts, double* d_out_tiles, void* hip_stream,
+                           rt_stats* stats /* nullable */);
+
+/* Scatters packed tiles (all parts concatenated in part order, as an all-gather delivers them) into a
+ * row-major width*height*3 image, both in device memory.  The un-interleave step after the RCCL gather. */
+int rt_assemble_tiles_device(uint32_t width, uint32_t height, uint32_t n_parts, const double* d_tiles_all_parts,
+                             double* d_out_rgb, void* hip_stream);
+
+/* Whole image, row-major, into DEVICE memory (n_parts == 1 path; no assembly step needed). */
+int rt_render_device(const rt_scene* scene, const rt_camera* camera, const rt_options* options,
+                     double* d_out_rgb, void* hip_stream, rt_stats* stats /* nullable */);
+
+/* `Color::as_scaled_values` (src/math/color.rs:55-66) + `Image::as_u8_rgb` (image.rs:84-89) on device:
+ * n_pixels*3 f64 -> n_pixels*3 u8 (round-half-away(clamp(v,0,1)*255), NaN -> 0). */
+int rt_quantize_device(const double* d_rgb, uint64_t n_values, uint8_t* d_out_u8, void* hip_stream);
+
+/* Traces arbitrary rays: `Integrator::color_at(Ray)` (src/shading/integrator.rs:68) for n rays given
+ * as HOST arrays origin[n][3], direction[n][3]; writes out_rgb[n][3] (host).  Used by the parity tests to
+ * replay the reference's unit-test rays through the device path. */
+int rt_trace_rays(const rt_scene* scene, const rt_options* options, uint32_t n, const double* origin,
+                  const double* direction, double* out_rgb);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RTCORE_H */
