@@ -1,0 +1,99 @@
+// rt_device.h — device-side f64 helpers and scene layout for the gfx950 render core.
+//
+// Operation order follows the reference exactly (no fma contraction: the file is compiled with
+// -ffp-contract=off), so EPSILON / acne-offset semantics match src/math/approx_eq.rs.
+// Reference lines are cited per function; nothing here is shared with oracle/.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/rtcore.h"
+
+#define RT_EPS 1.0e-8  // src/math/approx_eq.rs:1
+
+struct d3 {
+  double x, y, z;
+};
+
+__device__ __forceinline__ d3 mk3(double x, double y, double z) { return d3{x, y, z}; }
+__device__ __forceinline__ d3 add3(d3 a, d3 b) { return d3{a.x + b.x, a.y + b.y, a.z + b.z}; }
+__device__ __forceinline__ d3 sub3(d3 a, d3 b) { return d3{a.x - b.x, a.y - b.y, a.z - b.z}; }
+__device__ __forceinline__ d3 neg3(d3 a) { return d3{-a.x, -a.y, -a.z}; }
+__device__ __forceinline__ d3 scale3(d3 a, double f) { return d3{f * a.x, f * a.y, f * a.z}; }  // vector.rs:136-146
+__device__ __forceinline__ d3 cmul3(d3 a, d3 b) { return d3{a.x * b.x, a.y * b.y, a.z * b.z}; }  // color.rs:114-124
+__device__ __forceinline__ double dot3(d3 a, d3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }  // vector.rs:77-79
+__device__ __forceinline__ d3 cross3(d3 a, d3 b) {                                               // vector.rs:69-75
+  return d3{a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
+}
+__device__ __forceinline__ double mag3(d3 a) { return sqrt(a.x * a.x + a.y * a.y + a.z * a.z); }  // vector.rs:54-56
+__device__ __forceinline__ d3 normalize3(d3 a) {                                                  // vector.rs:57-67
+  double len = mag3(a);
+  if (len == 0.) return d3{0., 0., 0.};
+  return d3{a.x / len, a.y / len, a.z / len};
+}
+// vector.rs:81-83: *self - normal * 2. * self.dot(normal)
+__device__ __forceinline__ d3 reflect3(d3 v, d3 n) { return sub3(v, scale3(scale3(n, 2.), dot3(v, n))); }
+
+__device__ __forceinline__ bool approx_eq(double a, double b) { return a == b || fabs(a - b) < RT_EPS; }  // approx_eq.rs:16-20
+__device__ __forceinline__ bool sign_positive(double x) { return !__builtin_signbit(x); }
+
+// Matrix * Tuple (matrix.rs:316-337): the w term is kept (it can turn -0 into +0, and 1/±0 differs).
+__device__ __forceinline__ d3 mat_point(const double* __restrict__ m, d3 p) {
+  return d3{m[0] * p.x + m[1] * p.y + m[2] * p.z + m[3] * 1., m[4] * p.x + m[5] * p.y + m[6] * p.z + m[7] * 1.,
+            m[8] * p.x + m[9] * p.y + m[10] * p.z + m[11] * 1.};
+}
+__device__ __forceinline__ d3 mat_vector(const double* __restrict__ m, d3 p) {
+  return d3{m[0] * p.x + m[1] * p.y + m[2] * p.z + m[3] * 0., m[4] * p.x + m[5] * p.y + m[6] * p.z + m[7] * 0.,
+            m[8] * p.x + m[9] * p.y + m[10] * p.z + m[11] * 0.};
+}
+// Matrix::mul_transposed (matrix.rs:77-92) on a vector
+__device__ __forceinline__ d3 mat_transposed_vector(const double* __restrict__ m, d3 p) {
+  return d3{m[0] * p.x + m[4] * p.y + m[8] * p.z + m[12] * 0., m[1] * p.x + m[5] * p.y + m[9] * p.z + m[13] * 0.,
+            m[2] * p.x + m[6] * p.y + m[10] * p.z + m[14] * 0.};
+}
+
+// ---------------------------------------------------------------------------------------------
+// Device scene layout (built by rt_scene_create from rt_scene_desc)
+// ---------------------------------------------------------------------------------------------
+
+// One record per child reference, 64 B, 16-B aligned: a node visit reads its children's records
+// contiguously (reverse order), and a group child's bounding box and child range come with its record,
+// so descending costs no extra dependent load.  Record 0 is the scene root.
+struct __attribute__((aligned(16))) DevEntry {
+  double bb[6];    // bounding box of the child when it is a group (bounding_box.rs:25-28)
+  uint32_t ref;    // RT_MAKE_REF(kind, index)
+  uint32_t begin;  // group child: first record of ITS children
+  uint32_t count;  // group child: number of children
+  uint32_t pad;
+};
+
+struct DevScene {
+  const DevEntry* entries;
+  const uint4* prim_info;  // x shape, y material, z xform (RT_NONE = none), w geom
+  const uint32_t* prim_csg_left;
+  const double* xform_inv;  // [n][16]
+  const double* tri_isect;  // [n][9]  p1, e1, e2
+  const double* tri_norm;   // [n][9]  n1, n2, n3
+  const double* quadric;    // [n][2]  y_min, y_max
+  const uint8_t* quadric_closed;
+  const uint8_t* csg_op;
+  const uint8_t* csg_depth;
+  const uint32_t* csg_left;
+  const uint32_t* csg_right;
+  const double* material;  // [n][8]
+  const uint8_t* pattern_kind;
+  const double* pattern_c1;
+  const double* pattern_c2;
+  const double* pattern_inv;  // [n][16]
+  const double* light_pos;
+  const double* light_intensity;
+  uint32_t n_lights;
+  uint32_t n_prims;
+};
+
+struct DevOptions {
+  uint32_t n_offsets;
+  double offsets[5];
+  uint32_t max_depth;
+  uint32_t shadow_intensity;
+};

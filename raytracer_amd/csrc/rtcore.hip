@@ -1,0 +1,573 @@
+// rtcore.hip — kernels + C-ABI of librtcore.so (include/rtcore.h), gfx950 only.
+//
+// Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -shared rtcore.hip -o librtcore.so
+// (-ffp-contract=off: the reference never fuses a*b+c; see DESIGN.md "Numerics").
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "rt_kernels.h"
+
+// ---------------------------------------------------------------------------------------------
+// kernels
+// ---------------------------------------------------------------------------------------------
+#define RT_N_COUNTERS 8
+
+template <bool STATS>
+__device__ __forceinline__ void flush_counters(const Counters& c, unsigned long long* stats, uint32_t* overflow_flag) {
+  if (c.overflow) atomicOr(overflow_flag, 1u);
+  if (!STATS) return;
+  uint32_t v[RT_N_COUNTERS] = {c.rays_primary, c.rays_shadow, c.rays_reflect, c.rays_refract,
+                               c.node_visits,  c.tri_tests,   c.prim_tests,   c.overflow};
+  for (int k = 0; k < RT_N_COUNTERS; k++) {
+    unsigned long long x = v[k];
+    for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
+    if ((threadIdx.x & 63) == 0 && x) atomicAdd(&stats[k], x);
+  }
+}
+
+// XCD-aware tile order: consecutive workgroup ids are dealt round-robin over the 8 XCDs (each with its own L2),
+// so give every XCD a contiguous run of tiles (neighbouring tiles walk the same BVH subtrees).  Bijective for
+// any n (cdna_hip_programming.md T1).
+__device__ __forceinline__ uint32_t xcd_remap(uint32_t bid, uint32_t n) {
+  uint32_t q = n / 8, r = n % 8, xcd = bid % 8, k = bid / 8;
+  uint32_t base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return base + k;
+}
+
+// Renderer::color_at_pixel (renderer.rs:50-66) for one 8x8 tile per wavefront.
+template <bool STATS>
+__global__ __launch_bounds__(64) void render_tiles_kernel(DevScene s, rt_camera cam, DevOptions opt, uint32_t part,
+                                                          uint32_t n_parts, uint32_t tiles_x, uint32_t n_owned, int packed,
+                                                          double* __restrict__ out, unsigned long long* stats,
+                                                          uint32_t* overflow_flag) {
+  uint32_t k = xcd_remap(blockIdx.x, n_owned);
+  uint32_t tile = k * n_parts + part;
+  uint32_t lane = threadIdx.x;
+  uint32_t px = (tile % tiles_x) * RT_TILE_DIM + (lane & 7u);
+  uint32_t py = (tile / tiles_x) * RT_TILE_DIM + (lane >> 3);
+  Counters cnt = {0, 0, 0, 0, 0, 0, 0, 0};
+  bool inside = px < cam.width && py < cam.height;
+  d3 color = mk3(0., 0., 0.);
+  if (inside) {
+    double x = (double)px, y = (double)py;
+    for (uint32_t i = 0; i < opt.n_offsets; i++)
+      for (uint32_t j = 0; j < opt.n_offsets; j++) {  // dx outer, dy inner (renderer.rs:57-64)
+        d3 o, d;
+        camera_ray(cam, x + opt.offsets[i], y + opt.offsets[j], o, d);
+        if (STATS) cnt.rays_primary++;
+        color = add3(color, trace<STATS>(s, opt, o, d, cnt));
+      }
+    double nn = (double)(opt.n_offsets * opt.n_offsets);
+    color = mk3(color.x / nn, color.y / nn, color.z / nn);
+  }
+  if (packed) {
+    double* dst = out + ((size_t)k * 64 + lane) * 3;
+    dst[0] = color.x;
+    dst[1] = color.y;
+    dst[2] = color.z;
+  } else if (inside) {
+    double* dst = out + ((size_t)py * cam.width + px) * 3;
+    dst[0] = color.x;
+    dst[1] = color.y;
+    dst[2] = color.z;
+  }
+  flush_counters<STATS>(cnt, stats, overflow_flag);
+}
+
+// Packed tiles of all parts (part-major, as an all-gather delivers them) -> row-major image.
+__global__ __launch_bounds__(256) void assemble_tiles_kernel(uint32_t width, uint32_t height, uint32_t n_parts, uint32_t tiles_x,
+                                                             uint32_t n_tiles, const double* __restrict__ tiles,
+                                                             double* __restrict__ out) {
+  size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;  // one thread per (tile, lane)
+  if (gid >= (size_t)n_tiles * 64) return;
+  uint32_t tile = (uint32_t)(gid / 64), lane = (uint32_t)(gid % 64);
+  uint32_t part = tile % n_parts, k = tile / n_parts;
+  // offset of `part`'s block: sum of owned-tile counts of the parts before it
+  size_t base = 0;
+  for (uint32_t p = 0; p < part; p++) base += (n_tiles > p) ? (n_tiles - p + n_parts - 1) / n_parts : 0;
+  uint32_t px = (tile % tiles_x) * RT_TILE_DIM + (lane & 7u);
+  uint32_t py = (tile / tiles_x) * RT_TILE_DIM + (lane >> 3);
+  if (px >= width || py >= height) return;
+  const double* src = tiles + ((base + k) * 64 + lane) * 3;
+  double* dst = out + ((size_t)py * width + px) * 3;
+  dst[0] = src[0];
+  dst[1] = src[1];
+  dst[2] = src[2];
+}
+
+// Color::as_scaled_values (color.rs:55-66): clamp -> *255 -> round half away from zero -> u8 (NaN -> 0)
+__global__ __launch_bounds__(256) void quantize_kernel(const double* __restrict__ rgb, uint64_t n, uint8_t* __restrict__ out) {
+  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  double v = rgb[i];
+  uint8_t r = 0;
+  if (v == v) {
+    v = v < 0. ? 0. : (v > 1. ? 1. : v);
+    r = (uint8_t)round(v * 255.);
+  }
+  out[i] = r;
+}
+
+// Integrator::color_at for arbitrary rays (one lane per ray)
+__global__ __launch_bounds__(64) void trace_rays_kernel(DevScene s, DevOptions opt, uint32_t n, const double* __restrict__ origin,
+                                                        const double* __restrict__ dir, double* __restrict__ out,
+                                                        uint32_t* overflow_flag) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  Counters cnt = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (i < n) {
+    d3 o = mk3(origin[3 * i], origin[3 * i + 1], origin[3 * i + 2]);
+    d3 d = mk3(dir[3 * i], dir[3 * i + 1], dir[3 * i + 2]);
+    d3 c = trace<false>(s, opt, o, d, cnt);
+    out[3 * i] = c.x;
+    out[3 * i + 1] = c.y;
+    out[3 * i + 2] = c.z;
+  }
+  if (cnt.overflow) atomicOr(overflow_flag, 1u);
+}
+
+// ---------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string& msg) {
+  g_err = msg;
+  return code;
+}
+
+#define HIP_TRY(expr)                                                                              \
+  do {                                                                                             \
+    hipError_t _e = (expr);                                                                        \
+    if (_e != hipSuccess)                                                                          \
+      return fail(RT_ERR_DEVICE, std::string(#expr) + " failed: " + hipGetErrorString(_e));        \
+  } while (0)
+
+struct DeviceBuffers {
+  std::vector<void*> ptrs;
+  ~DeviceBuffers() {
+    for (void* p : ptrs)
+      if (p) (void)hipFree(p);
+  }
+};
+
+}  // namespace
+
+struct rt_scene {
+  DevScene dev;
+  DeviceBuffers bufs;
+  int device = 0;
+  unsigned long long* d_stats = nullptr;  // RT_N_COUNTERS counters
+  uint32_t* d_overflow = nullptr;
+  size_t bytes = 0;
+  uint32_t stack_need = 0;
+};
+
+namespace {
+
+template <class T>
+int upload(rt_scene* sc, const std::vector<T>& host, const T** out) {
+  size_t bytes = host.size() * sizeof(T);
+  void* p = nullptr;
+  HIP_TRY(hipMalloc(&p, bytes ? bytes : 16));
+  sc->bufs.ptrs.push_back(p);
+  if (bytes) HIP_TRY(hipMemcpy(p, host.data(), bytes, hipMemcpyHostToDevice));
+  sc->bytes += bytes;
+  *out = (const T*)p;
+  return RT_OK;
+}
+
+bool ref_ok(const rt_scene_desc* d, uint32_t ref) {
+  uint32_t kind = ref >> RT_REF_KIND_SHIFT, idx = ref & RT_REF_INDEX_MASK;
+  if (kind == RT_REF_NODE) return idx < d->n_nodes;
+  if (kind == RT_REF_PRIM) return idx < d->n_prims;
+  if (kind == RT_REF_CSG) return idx < d->n_csgs;
+  return false;
+}
+
+// Worst-case traversal stack (group.rs:176-199): while child i of a node is being processed, its later
+// group siblings are still on the stack.
+uint32_t stack_need(const rt_scene_desc* d, uint32_t node, std::vector<int64_t>& memo, int guard) {
+  if (memo[node] >= 0) return (uint32_t)memo[node];
+  if (guard > 100000) return 1u << 30;
+  uint32_t b = d->node_child_begin[node], e = d->node_child_begin[node + 1];
+  std::vector<uint32_t> groups;
+  for (uint32_t i = b; i < e; i++)
+    if ((d->child_ref[i] >> RT_REF_KIND_SHIFT) == RT_REF_NODE) groups.push_back(d->child_ref[i] & RT_REF_INDEX_MASK);
+  uint32_t k = (uint32_t)groups.size(), need = k;
+  for (uint32_t i = 0; i < k; i++) {
+    uint32_t sub = stack_need(d, groups[i], memo, guard + 1);
+    uint32_t v = (k - 1 - i) + sub;
+    if (v > need) need = v;
+  }
+  memo[node] = need;
+  return need;
+}
+
+int validate(const rt_scene_desc* d) {
+  if (!d) return fail(RT_ERR_INVALID_ARGUMENT, "scene is NULL");
+  if (d->abi_version != RT_ABI_VERSION) return fail(RT_ERR_INVALID_ARGUMENT, "rt_scene_desc.abi_version mismatch");
+  if (d->n_nodes == 0 || !d->node_bbox || !d->node_child_begin)
+    return fail(RT_ERR_INVALID_ARGUMENT, "scene needs at least the root node (node 0)");
+  if (d->n_child_refs && !d->child_ref) return fail(RT_ERR_INVALID_ARGUMENT, "child_ref is NULL");
+  if (d->node_child_begin[0] != 0 || d->node_child_begin[d->n_nodes] != d->n_child_refs)
+    return fail(RT_ERR_INVALID_ARGUMENT, "node_child_begin must start at 0 and end at n_child_refs");
+  for (uint32_t i = 0; i < d->n_nodes; i++)
+    if (d->node_child_begin[i] > d->node_child_begin[i + 1]) return fail(RT_ERR_INVALID_ARGUMENT, "node_child_begin not monotonic");
+  for (uint32_t i = 0; i < d->n_child_refs; i++)
+    if (!ref_ok(d, d->child_ref[i])) return fail(RT_ERR_INVALID_ARGUMENT, "child_ref out of range");
+  if (d->n_prims && (!d->prim_shape || !d->prim_material || !d->prim_xform || !d->prim_geom || !d->prim_csg_left))
+    return fail(RT_ERR_INVALID_ARGUMENT, "primitive tables missing");
+  if (d->n_materials == 0 && d->n_prims) return fail(RT_ERR_INVALID_ARGUMENT, "no materials");
+  for (uint32_t i = 0; i < d->n_prims; i++) {
+    uint8_t sh = d->prim_shape[i];
+    if (sh > RT_SHAPE_BBOX) return fail(RT_ERR_INVALID_ARGUMENT, "unknown shape tag");
+    if (d->prim_material[i] >= d->n_materials) return fail(RT_ERR_INVALID_ARGUMENT, "prim_material out of range");
+    if (d->prim_xform[i] != RT_NONE && d->prim_xform[i] >= d->n_xforms) return fail(RT_ERR_INVALID_ARGUMENT, "prim_xform out of range");
+    if (sh == RT_SHAPE_TRIANGLE || sh == RT_SHAPE_SMOOTH_TRIANGLE) {
+      if (d->prim_geom[i] >= d->n_tris) return fail(RT_ERR_INVALID_ARGUMENT, "triangle index out of range");
+    } else if (sh == RT_SHAPE_CYLINDER || sh == RT_SHAPE_CONE) {
+      if (d->prim_geom[i] >= d->n_quadrics) return fail(RT_ERR_INVALID_ARGUMENT, "quadric index out of range");
+    }
+  }
+  if (d->n_tris && (!d->tri_p1 || !d->tri_e1 || !d->tri_e2 || !d->tri_n1 || !d->tri_n2 || !d->tri_n3))
+    return fail(RT_ERR_INVALID_ARGUMENT, "triangle tables missing");
+  if (d->n_xforms && !d->xform_inv) return fail(RT_ERR_INVALID_ARGUMENT, "xform_inv is NULL");
+  if (d->n_quadrics && (!d->quadric_y_min || !d->quadric_y_max || !d->quadric_closed))
+    return fail(RT_ERR_INVALID_ARGUMENT, "quadric tables missing");
+  if (d->n_materials && (!d->material || !d->pattern_kind || !d->pattern_c1 || !d->pattern_c2 || !d->pattern_inv))
+    return fail(RT_ERR_INVALID_ARGUMENT, "material tables missing");
+  for (uint32_t i = 0; i < d->n_materials; i++)
+    if (d->pattern_kind[i] > RT_PATTERN_TEST) return fail(RT_ERR_INVALID_ARGUMENT, "unknown pattern tag");
+  if (d->n_lights && (!d->light_pos || !d->light_intensity)) return fail(RT_ERR_INVALID_ARGUMENT, "light tables missing");
+  if (d->n_csgs && (!d->csg_op || !d->csg_left || !d->csg_right || !d->csg_depth))
+    return fail(RT_ERR_INVALID_ARGUMENT, "csg tables missing");
+  for (uint32_t i = 0; i < d->n_csgs; i++) {
+    if (d->csg_op[i] > RT_CSG_DIFFERENCE) return fail(RT_ERR_INVALID_ARGUMENT, "unknown csg op");
+    if (!ref_ok(d, d->csg_left[i]) || !ref_ok(d, d->csg_right[i])) return fail(RT_ERR_INVALID_ARGUMENT, "csg child out of range");
+    if (d->csg_depth[i] >= RT_CSG_NEST_MAX)
+      return fail(RT_ERR_UNSUPPORTED, "CSG objects nested deeper than RT_CSG_NEST_MAX (4) are not supported on the device");
+    for (uint32_t ref : {d->csg_left[i], d->csg_right[i]})
+      if ((ref >> RT_REF_KIND_SHIFT) == RT_REF_NODE)
+        return fail(RT_ERR_UNSUPPORTED, "a group as a CSG operand is not supported on the device (primitives and nested CSG are)");
+  }
+  return RT_OK;
+}
+
+DevOptions dev_options(const rt_options* o) {
+  DevOptions d;
+  d.n_offsets = o->n_offsets;
+  for (int i = 0; i < 5; i++) d.offsets[i] = o->offsets[i];
+  d.max_depth = o->max_depth;
+  d.shadow_intensity = o->shadow_intensity;
+  return d;
+}
+
+int check_render_args(const rt_scene* scene, const rt_camera* cam, const rt_options* opt) {
+  if (!scene || !cam || !opt) return fail(RT_ERR_INVALID_ARGUMENT, "scene, camera and options are required");
+  if (cam->width == 0 || cam->height == 0) return fail(RT_ERR_INVALID_ARGUMENT, "camera width/height must be > 0");
+  if (opt->n_offsets < 1 || opt->n_offsets > 5) return fail(RT_ERR_INVALID_ARGUMENT, "n_offsets must be 1..5");
+  if (opt->max_depth > RT_MAX_DEPTH)
+    return fail(RT_ERR_UNSUPPORTED, "max_depth exceeds the device limit RT_MAX_DEPTH (16)");
+  return RT_OK;
+}
+
+uint32_t tiles_total(uint32_t w, uint32_t h, uint32_t* tiles_x) {
+  uint32_t tx = (w + RT_TILE_DIM - 1) / RT_TILE_DIM, ty = (h + RT_TILE_DIM - 1) / RT_TILE_DIM;
+  if (tiles_x) *tiles_x = tx;
+  return tx * ty;
+}
+
+int launch_render(const rt_scene* scene, const rt_camera* cam, const rt_options* opt, uint32_t part, uint32_t n_parts, int packed,
+                  double* d_out, hipStream_t stream, rt_stats* stats) {
+  int rc = check_render_args(scene, cam, opt);
+  if (rc) return rc;
+  if (!d_out) return fail(RT_ERR_INVALID_ARGUMENT, "output buffer is NULL");
+  if (n_parts == 0 || part >= n_parts) return fail(RT_ERR_INVALID_ARGUMENT, "part must be < n_parts");
+  uint32_t tiles_x;
+  uint32_t n_tiles = tiles_total(cam->width, cam->height, &tiles_x);
+  uint32_t n_owned = n_tiles > part ? (n_tiles - part + n_parts - 1) / n_parts : 0;
+  HIP_TRY(hipMemsetAsync(scene->d_overflow, 0, sizeof(uint32_t), stream));
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (stats) {
+    HIP_TRY(hipMemsetAsync(scene->d_stats, 0, RT_N_COUNTERS * sizeof(unsigned long long), stream));
+    HIP_TRY(hipEventCreate(&e0));
+    HIP_TRY(hipEventCreate(&e1));
+    HIP_TRY(hipEventRecord(e0, stream));
+  }
+  if (n_owned) {
+    DevOptions dopt = dev_options(opt);
+    if (stats)
+      hipLaunchKernelGGL(render_tiles_kernel<true>, dim3(n_owned), dim3(64), 0, stream, scene->dev, *cam, dopt, part, n_parts,
+                         tiles_x, n_owned, packed, d_out, scene->d_stats, scene->d_overflow);
+    else
+      hipLaunchKernelGGL(render_tiles_kernel<false>, dim3(n_owned), dim3(64), 0, stream, scene->dev, *cam, dopt, part, n_parts,
+                         tiles_x, n_owned, packed, d_out, scene->d_stats, scene->d_overflow);
+    HIP_TRY(hipGetLastError());
+  }
+  if (stats) {
+    HIP_TRY(hipEventRecord(e1, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    unsigned long long h[RT_N_COUNTERS];
+    uint32_t ovf = 0;
+    HIP_TRY(hipMemcpy(h, scene->d_stats, sizeof(h), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(&ovf, scene->d_overflow, sizeof(ovf), hipMemcpyDeviceToHost));
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    std::memset(stats, 0, sizeof(*stats));
+    stats->rays_primary = h[0];
+    stats->rays_shadow = h[1];
+    stats->rays_reflect = h[2];
+    stats->rays_refract = h[3];
+    stats->node_visits = h[4];
+    stats->tri_tests = h[5];
+    stats->prim_tests = h[6];
+    stats->overflow_pixels = h[7];
+    stats->ms_kernel = ms;
+    if (ovf) return fail(RT_ERR_OVERFLOW, "a per-ray bounded list (BVH stack or CSG hit list) overflowed on the device");
+  }
+  return RT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+uint32_t rt_abi_version(void) { return RT_ABI_VERSION; }
+const char* rt_last_error(void) { return g_err.c_str(); }
+
+int rt_device_count(void) {
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess) {
+    g_err = std::string("hipGetDeviceCount failed: ") + hipGetErrorString(e);
+    return RT_ERR_DEVICE;
+  }
+  return n;
+}
+
+int rt_scene_create(const rt_scene_desc* d, rt_scene** out) {
+  if (!out) return fail(RT_ERR_INVALID_ARGUMENT, "out is NULL");
+  *out = nullptr;
+  int rc = validate(d);
+  if (rc) return rc;
+
+  std::vector<int64_t> memo(d->n_nodes, -1);
+  uint32_t need = stack_need(d, 0, memo, 0);
+  if (need < 1) need = 1;
+  if (need > RT_STACK_MAX)
+    return fail(RT_ERR_UNSUPPORTED, "the BVH needs a traversal stack of " + std::to_string(need) + " entries; the device limit is " +
+                                        std::to_string(RT_STACK_MAX));
+
+  // child records: record 0 = root, then node i's children at 1 + node_child_begin[i]
+  std::vector<DevEntry> entries((size_t)d->n_child_refs + 1);
+  auto fill_node_fields = [&](DevEntry& e, uint32_t node) {
+    std::memcpy(e.bb, d->node_bbox + (size_t)node * 6, sizeof(double) * 6);
+    e.begin = 1 + d->node_child_begin[node];
+    e.count = d->node_child_begin[node + 1] - d->node_child_begin[node];
+  };
+  std::memset(entries.data(), 0, entries.size() * sizeof(DevEntry));
+  entries[0].ref = RT_MAKE_REF(RT_REF_NODE, 0);
+  fill_node_fields(entries[0], 0);
+  for (uint32_t i = 0; i < d->n_child_refs; i++) {
+    DevEntry& e = entries[(size_t)i + 1];
+    e.ref = d->child_ref[i];
+    if ((e.ref >> RT_REF_KIND_SHIFT) == RT_REF_NODE) fill_node_fields(e, e.ref & RT_REF_INDEX_MASK);
+  }
+  std::vector<uint4> prim_info(d->n_prims);
+  for (uint32_t i = 0; i < d->n_prims; i++) prim_info[i] = make_uint4(d->prim_shape[i], d->prim_material[i], d->prim_xform[i], d->prim_geom[i]);
+  std::vector<double> tri_isect((size_t)d->n_tris * 9), tri_norm((size_t)d->n_tris * 9);
+  for (size_t i = 0; i < d->n_tris; i++)
+    for (int k = 0; k < 3; k++) {
+      tri_isect[i * 9 + k] = d->tri_p1[i * 3 + k];
+      tri_isect[i * 9 + 3 + k] = d->tri_e1[i * 3 + k];
+      tri_isect[i * 9 + 6 + k] = d->tri_e2[i * 3 + k];
+      tri_norm[i * 9 + k] = d->tri_n1[i * 3 + k];
+      tri_norm[i * 9 + 3 + k] = d->tri_n2[i * 3 + k];
+      tri_norm[i * 9 + 6 + k] = d->tri_n3[i * 3 + k];
+    }
+  std::vector<double> quadric((size_t)d->n_quadrics * 2);
+  for (size_t i = 0; i < d->n_quadrics; i++) {
+    quadric[i * 2] = d->quadric_y_min[i];
+    quadric[i * 2 + 1] = d->quadric_y_max[i];
+  }
+
+  rt_scene* sc = new rt_scene();
+  (void)hipGetDevice(&sc->device);
+  sc->stack_need = need;
+#define UP(vec, field)                                 \
+  do {                                                 \
+    rc = upload(sc, vec, &sc->dev.field);              \
+    if (rc) {                                          \
+      delete sc;                                       \
+      return rc;                                       \
+    }                                                  \
+  } while (0)
+#define UPA(T, ptr, n, field)                          \
+  do {                                                 \
+    std::vector<T> _v((ptr), (ptr) + (size_t)(n));     \
+    UP(_v, field);                                     \
+  } while (0)
+  UP(entries, entries);
+  UP(prim_info, prim_info);
+  UPA(uint32_t, d->prim_csg_left, d->n_prims, prim_csg_left);
+  UPA(double, d->xform_inv, (size_t)d->n_xforms * 16, xform_inv);
+  UP(tri_isect, tri_isect);
+  UP(tri_norm, tri_norm);
+  UP(quadric, quadric);
+  UPA(uint8_t, d->quadric_closed, d->n_quadrics, quadric_closed);
+  UPA(uint8_t, d->csg_op, d->n_csgs, csg_op);
+  UPA(uint8_t, d->csg_depth, d->n_csgs, csg_depth);
+  UPA(uint32_t, d->csg_left, d->n_csgs, csg_left);
+  UPA(uint32_t, d->csg_right, d->n_csgs, csg_right);
+  UPA(double, d->material, (size_t)d->n_materials * RT_MAT_STRIDE, material);
+  UPA(uint8_t, d->pattern_kind, d->n_materials, pattern_kind);
+  UPA(double, d->pattern_c1, (size_t)d->n_materials * 3, pattern_c1);
+  UPA(double, d->pattern_c2, (size_t)d->n_materials * 3, pattern_c2);
+  UPA(double, d->pattern_inv, (size_t)d->n_materials * 16, pattern_inv);
+  UPA(double, d->light_pos, (size_t)d->n_lights * 3, light_pos);
+  UPA(double, d->light_intensity, (size_t)d->n_lights * 3, light_intensity);
+#undef UP
+#undef UPA
+  sc->dev.n_lights = d->n_lights;
+  sc->dev.n_prims = d->n_prims;
+  void* p = nullptr;
+  if (hipMalloc(&p, RT_N_COUNTERS * sizeof(unsigned long long)) != hipSuccess) {
+    delete sc;
+    return fail(RT_ERR_DEVICE, "hipMalloc(stats) failed");
+  }
+  sc->bufs.ptrs.push_back(p);
+  sc->d_stats = (unsigned long long*)p;
+  if (hipMalloc(&p, 16) != hipSuccess) {
+    delete sc;
+    return fail(RT_ERR_DEVICE, "hipMalloc(overflow) failed");
+  }
+  sc->bufs.ptrs.push_back(p);
+  sc->d_overflow = (uint32_t*)p;
+  *out = sc;
+  return RT_OK;
+}
+
+void rt_scene_destroy(rt_scene* scene) { delete scene; }
+
+uint32_t rt_tile_count(uint32_t width, uint32_t height, uint32_t part, uint32_t n_parts) {
+  if (n_parts == 0 || part >= n_parts) return 0;
+  uint32_t n = tiles_total(width, height, nullptr);
+  return n > part ? (n - part + n_parts - 1) / n_parts : 0;
+}
+
+int rt_render_tiles_device(const rt_scene* scene, const rt_camera* camera, const rt_options* options, uint32_t part,
+                           uint32_t n_parts, double* d_out_tiles, void* hip_stream, rt_stats* stats) {
+  return launch_render(scene, camera, options, part, n_parts, 1, d_out_tiles, (hipStream_t)hip_stream, stats);
+}
+
+int rt_render_device(const rt_scene* scene, const rt_camera* camera, const rt_options* options, double* d_out_rgb, void* hip_stream,
+                     rt_stats* stats) {
+  return launch_render(scene, camera, options, 0, 1, 0, d_out_rgb, (hipStream_t)hip_stream, stats);
+}
+
+int rt_assemble_tiles_device(uint32_t width, uint32_t height, uint32_t n_parts, const double* d_tiles_all_parts, double* d_out_rgb,
+                             void* hip_stream) {
+  if (!d_tiles_all_parts || !d_out_rgb || n_parts == 0 || width == 0 || height == 0)
+    return fail(RT_ERR_INVALID_ARGUMENT, "bad arguments to rt_assemble_tiles_device");
+  uint32_t tiles_x;
+  uint32_t n_tiles = tiles_total(width, height, &tiles_x);
+  size_t threads = (size_t)n_tiles * 64;
+  hipLaunchKernelGGL(assemble_tiles_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)hip_stream, width,
+                     height, n_parts, tiles_x, n_tiles, d_tiles_all_parts, d_out_rgb);
+  HIP_TRY(hipGetLastError());
+  return RT_OK;
+}
+
+int rt_quantize_device(const double* d_rgb, uint64_t n_values, uint8_t* d_out_u8, void* hip_stream) {
+  if (!d_rgb || !d_out_u8) return fail(RT_ERR_INVALID_ARGUMENT, "bad arguments to rt_quantize_device");
+  if (n_values == 0) return RT_OK;
+  hipLaunchKernelGGL(quantize_kernel, dim3((unsigned)((n_values + 255) / 256)), dim3(256), 0, (hipStream_t)hip_stream, d_rgb,
+                     n_values, d_out_u8);
+  HIP_TRY(hipGetLastError());
+  return RT_OK;
+}
+
+int rt_trace_rays(const rt_scene* scene, const rt_options* options, uint32_t n, const double* origin, const double* direction,
+                  double* out_rgb) {
+  if (!scene || !options || !origin || !direction || !out_rgb) return fail(RT_ERR_INVALID_ARGUMENT, "bad arguments to rt_trace_rays");
+  if (options->max_depth > RT_MAX_DEPTH) return fail(RT_ERR_UNSUPPORTED, "max_depth exceeds RT_MAX_DEPTH");
+  if (n == 0) return RT_OK;
+  size_t bytes = (size_t)n * 3 * sizeof(double);
+  double *d_o = nullptr, *d_d = nullptr, *d_c = nullptr;
+  HIP_TRY(hipMalloc((void**)&d_o, bytes));
+  HIP_TRY(hipMalloc((void**)&d_d, bytes));
+  HIP_TRY(hipMalloc((void**)&d_c, bytes));
+  int rc = RT_OK;
+  do {
+    if (hipMemcpy(d_o, origin, bytes, hipMemcpyHostToDevice) != hipSuccess || hipMemcpy(d_d, direction, bytes, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemset(scene->d_overflow, 0, sizeof(uint32_t)) != hipSuccess) {
+      rc = fail(RT_ERR_DEVICE, "upload of rays failed");
+      break;
+    }
+    hipLaunchKernelGGL(trace_rays_kernel, dim3((n + 63) / 64), dim3(64), 0, 0, scene->dev, dev_options(options), n, d_o, d_d, d_c,
+                       scene->d_overflow);
+    uint32_t ovf = 0;
+    if (hipDeviceSynchronize() != hipSuccess || hipMemcpy(out_rgb, d_c, bytes, hipMemcpyDeviceToHost) != hipSuccess ||
+        hipMemcpy(&ovf, scene->d_overflow, sizeof(ovf), hipMemcpyDeviceToHost) != hipSuccess) {
+      rc = fail(RT_ERR_DEVICE, std::string("trace_rays kernel failed: ") + hipGetErrorString(hipGetLastError()));
+      break;
+    }
+    if (ovf) rc = fail(RT_ERR_OVERFLOW, "a per-ray bounded list overflowed on the device");
+  } while (0);
+  (void)hipFree(d_o);
+  (void)hipFree(d_d);
+  (void)hipFree(d_c);
+  return rc;
+}
+
+int rt_render(const rt_scene_desc* scene_desc, const rt_camera* camera, const rt_options* options, double* out_rgb, rt_stats* stats) {
+  if (!out_rgb || !camera) return fail(RT_ERR_INVALID_ARGUMENT, "out_rgb and camera are required");
+  hipEvent_t e0, e1, e2, e3;
+  HIP_TRY(hipEventCreate(&e0));
+  HIP_TRY(hipEventCreate(&e1));
+  HIP_TRY(hipEventCreate(&e2));
+  HIP_TRY(hipEventCreate(&e3));
+  HIP_TRY(hipEventRecord(e0, 0));
+  rt_scene* sc = nullptr;
+  int rc = rt_scene_create(scene_desc, &sc);
+  if (rc) return rc;
+  HIP_TRY(hipEventRecord(e1, 0));
+  size_t bytes = (size_t)camera->width * camera->height * 3 * sizeof(double);
+  double* d_out = nullptr;
+  if (hipMalloc((void**)&d_out, bytes ? bytes : 16) != hipSuccess) {
+    rt_scene_destroy(sc);
+    return fail(RT_ERR_DEVICE, "hipMalloc(image) failed");
+  }
+  rt_stats local;
+  rc = launch_render(sc, camera, options, 0, 1, 0, d_out, 0, &local);
+  if (rc == RT_OK || rc == RT_ERR_OVERFLOW) {
+    (void)hipEventRecord(e2, 0);
+    if (hipMemcpy(out_rgb, d_out, bytes, hipMemcpyDeviceToHost) != hipSuccess) rc = fail(RT_ERR_DEVICE, "download of the image failed");
+    (void)hipEventRecord(e3, 0);
+    (void)hipEventSynchronize(e3);
+    float up = 0.f, down = 0.f;
+    (void)hipEventElapsedTime(&up, e0, e1);
+    (void)hipEventElapsedTime(&down, e2, e3);
+    local.ms_upload = up;
+    local.ms_download = down;
+    if (stats) *stats = local;
+  }
+  (void)hipFree(d_out);
+  rt_scene_destroy(sc);
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  (void)hipEventDestroy(e2);
+  (void)hipEventDestroy(e3);
+  return rc;
+}
+
+}  // extern "C"
