@@ -210,10 +210,12 @@ int rt_render_tiles_device(const rt_scene* scene, const rt_camera* camera, const
                            uint32_t part, uint32_t n_parts, double* d_out_tiles, void* hip_stream,
                            rt_stats* stats /* nullable */);
 
-/* Scatters packed tiles (all parts concatenated in part order, as an all-gather delivers them) into a
- * row-major width*height*3 image, both in device memory.  The un-interleave step after the RCCL gather. */
-int rt_assemble_tiles_device(uint32_t width, uint32_t height, uint32_t n_parts, const double* d_tiles_all_parts,
-                             double* d_out_rgb, void* hip_stream);
+/* Scatters packed tiles of all parts (in part order, as a gather delivers them) into a row-major
+ * width*height*3 image, both in device memory.  The un-interleave step after the RCCL gather.
+ * part_stride_tiles: distance between the blocks of consecutive parts, in tiles (a gather of equally sized,
+ * padded buffers); 0 means the blocks are tightly concatenated (block p holds rt_tile_count(.., p, n_parts) tiles). */
+int rt_assemble_tiles_device(uint32_t width, uint32_t height, uint32_t n_parts, uint32_t part_stride_tiles,
+                             const double* d_tiles_all_parts, double* d_out_rgb, void* hip_stream);
 
 /* Whole image, row-major, into DEVICE memory (n_parts == 1 path; no assembly step needed). */
 int rt_render_device(const rt_scene* scene, const rt_camera* camera, const rt_options* options,

@@ -35,7 +35,7 @@ def lib() -> C.CDLL:
     L.rto_render_region.argtypes = [sp, cp, op, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_int, pd, stp]
     L.rto_render.argtypes = [sp, cp, op, C.c_int, C.c_int, pd, stp]
     L.rto_color_at.argtypes = [sp, op, pd, pd, pd]
-    L.rto_intersect_all.argtypes = [sp, pd, pd, C.c_int, pd, C.POINTER(C.c_uint32)]
+    L.rto_intersect_all.argtypes = [sp, pd, pd, C.c_uint32, C.c_int, pd, C.POINTER(C.c_uint32)]
     L.rto_hit_computations.argtypes = [sp, pd, pd, pd]
     L.rto_shadow_intensity.argtypes = [sp, op, C.c_uint32, pd]
     L.rto_shadow_intensity.restype = C.c_double
@@ -75,10 +75,13 @@ def color_at(flat, options, origin, direction):
     return out
 
 
-def intersect_all(flat, origin, direction, max_out=64):
+def intersect_all(flat, origin, direction, max_out=64, direct_ref=None):
+    """direct_ref=None: through the scene root group (with its bounding-box test); otherwise a child reference
+    (kind << 30 | index) intersected directly, like Object::intersection_times_testing (object.rs:214)."""
     t = np.zeros(max_out)
     prim = np.zeros(max_out, dtype=np.uint32)
-    n = lib().rto_intersect_all(C.byref(flat.desc), N.dptr(origin), N.dptr(direction), max_out, _p(t),
+    ref = N.RT_NONE if direct_ref is None else int(direct_ref)
+    n = lib().rto_intersect_all(C.byref(flat.desc), N.dptr(origin), N.dptr(direction), ref, max_out, _p(t),
                                 prim.ctypes.data_as(C.POINTER(C.c_uint32)))
     n = min(n, max_out)
     return t[:n].copy(), prim[:n].copy()

@@ -724,14 +724,18 @@ void rto_color_at(const rt_scene_desc* scene, const rt_options* opt, const doubl
 }
 
 // Integrator::intersect_testing (integrator.rs:256-260): keep-all collector, sorted. Returns the count.
-int rto_intersect_all(const rt_scene_desc* scene, const double* origin, const double* dir, int max_out, double* out_t,
-                      uint32_t* out_prim) {
+// direct_ref == RT_NONE intersects the scene root group; otherwise that object alone, without the root's
+// bounding-box test (Object::intersect_to_collection, object.rs:204-208).
+int rto_intersect_all(const rt_scene_desc* scene, const double* origin, const double* dir, uint32_t direct_ref, int max_out,
+                      double* out_t, uint32_t* out_prim) {
   Counters c;
   rt_options opt{};
   Ctx cx{scene, opt, false, &c};
   Collector col;
   col.skip_redundant = false;
-  group_intersect(cx, 0, make_ray({origin[0], origin[1], origin[2]}, {dir[0], dir[1], dir[2]}), col);
+  Ray ray = make_ray({origin[0], origin[1], origin[2]}, {dir[0], dir[1], dir[2]});
+  if (direct_ref == RT_NONE) group_intersect(cx, 0, ray, col);
+  else ref_intersect(cx, direct_ref, ray, col);
   std::stable_sort(col.vec.begin(), col.vec.end(), [](const Inter& a, const Inter& b) { return a.t < b.t; });
   int n = 0;
   for (const Inter& i : col.vec) {

@@ -80,16 +80,17 @@ __global__ __launch_bounds__(64) void render_tiles_kernel(DevScene s, rt_camera 
 }
 
 // Packed tiles of all parts (part-major, as an all-gather delivers them) -> row-major image.
-__global__ __launch_bounds__(256) void assemble_tiles_kernel(uint32_t width, uint32_t height, uint32_t n_parts, uint32_t tiles_x,
-                                                             uint32_t n_tiles, const double* __restrict__ tiles,
+__global__ __launch_bounds__(256) void assemble_tiles_kernel(uint32_t width, uint32_t height, uint32_t n_parts, uint32_t part_stride,
+                                                             uint32_t tiles_x, uint32_t n_tiles, const double* __restrict__ tiles,
                                                              double* __restrict__ out) {
   size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;  // one thread per (tile, lane)
   if (gid >= (size_t)n_tiles * 64) return;
   uint32_t tile = (uint32_t)(gid / 64), lane = (uint32_t)(gid % 64);
   uint32_t part = tile % n_parts, k = tile / n_parts;
   // offset of `part`'s block: sum of owned-tile counts of the parts before it
-  size_t base = 0;
-  for (uint32_t p = 0; p < part; p++) base += (n_tiles > p) ? (n_tiles - p + n_parts - 1) / n_parts : 0;
+  size_t base = (size_t)part * part_stride;
+  if (part_stride == 0)
+    for (uint32_t p = 0; p < part; p++) base += (n_tiles > p) ? (n_tiles - p + n_parts - 1) / n_parts : 0;
   uint32_t px = (tile % tiles_x) * RT_TILE_DIM + (lane & 7u);
   uint32_t py = (tile / tiles_x) * RT_TILE_DIM + (lane >> 3);
   if (px >= width || py >= height) return;
@@ -474,15 +475,15 @@ int rt_render_device(const rt_scene* scene, const rt_camera* camera, const rt_op
   return launch_render(scene, camera, options, 0, 1, 0, d_out_rgb, (hipStream_t)hip_stream, stats);
 }
 
-int rt_assemble_tiles_device(uint32_t width, uint32_t height, uint32_t n_parts, const double* d_tiles_all_parts, double* d_out_rgb,
-                             void* hip_stream) {
+int rt_assemble_tiles_device(uint32_t width, uint32_t height, uint32_t n_parts, uint32_t part_stride_tiles,
+                             const double* d_tiles_all_parts, double* d_out_rgb, void* hip_stream) {
   if (!d_tiles_all_parts || !d_out_rgb || n_parts == 0 || width == 0 || height == 0)
     return fail(RT_ERR_INVALID_ARGUMENT, "bad arguments to rt_assemble_tiles_device");
   uint32_t tiles_x;
   uint32_t n_tiles = tiles_total(width, height, &tiles_x);
   size_t threads = (size_t)n_tiles * 64;
   hipLaunchKernelGGL(assemble_tiles_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)hip_stream, width,
-                     height, n_parts, tiles_x, n_tiles, d_tiles_all_parts, d_out_rgb);
+                     height, n_parts, part_stride_tiles, tiles_x, n_tiles, d_tiles_all_parts, d_out_rgb);
   HIP_TRY(hipGetLastError());
   return RT_OK;
 }

@@ -83,9 +83,10 @@ def tile_count(width: int, height: int, part: int, n_parts: int) -> int:
     return N.core_lib().rt_tile_count(width, height, part, n_parts)
 
 
-def assemble_tiles(width: int, height: int, n_parts: int, d_tiles_ptr: int, d_out_ptr: int, stream: int = 0):
-    _check(N.core_lib().rt_assemble_tiles_device(width, height, n_parts, C.c_void_p(d_tiles_ptr), C.c_void_p(d_out_ptr),
-                                                 C.c_void_p(stream)))
+def assemble_tiles(width: int, height: int, n_parts: int, part_stride_tiles: int, d_tiles_ptr: int, d_out_ptr: int,
+                   stream: int = 0):
+    _check(N.core_lib().rt_assemble_tiles_device(width, height, n_parts, part_stride_tiles, C.c_void_p(d_tiles_ptr),
+                                                 C.c_void_p(d_out_ptr), C.c_void_p(stream)))
 
 
 def quantize_device(d_rgb_ptr: int, n_values: int, d_out_ptr: int, stream: int = 0):

@@ -1,0 +1,259 @@
+"""Parity tests proper: the HIP path, called through the C-ABI (librtcore.so), against the CPU oracle on the same
+flattened scene, against the reference's golden PNGs, and — at BASELINE.json's full sizes — through
+size-independent properties (tile partition == whole image, supersample linearity, idempotence).
+
+Bar (north star): <= 1 LSB per 8-bit channel on >= 99.9 % of pixels.  Tighter bars asserted here: f64 pixels within
+1e-9 absolute of the oracle (everything except pow() in the specular term is bit-exact by construction) and u8
+identical on >= 99.9 % of pixels."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+from PIL import Image
+
+import oracle as O
+from conftest import (FRAC_1_SQRT_2, GOLDEN, N, S, default_testing_builder, options_for_tests, translation)
+from raytracer_amd import distributed as D
+from raytracer_amd import renderer as R
+from raytracer_amd import scene_yaml as Y
+
+pytestmark = pytest.mark.gpu
+
+F64_TOL = 1e-9
+IMAGES = ["chapters/cubes", "chapters/cylinders", "chapters/groups", "chapters/making-patterns", "chapters/making-scene",
+          "chapters/planes", "chapters/reflections", "chapters/refractions", "chapters/shadows", "general/cover",
+          "general/dragons", "general/local-transforms"]
+ANIMS = ["csg-lens", "refractions", "rotating-dragon", "sphere"]
+
+
+def scene_path(kind, name):
+    return os.path.join(GOLDEN, "scenes", kind, name + ".yml")
+
+
+def check_against_oracle(flat, cam, opt, gpu=None):
+    if gpu is None:
+        gpu, _ = R.render(flat, cam, opt)
+    cpu, _ = O.render(flat, cam, opt)
+    assert np.all(np.isfinite(gpu))
+    assert float(np.abs(gpu - cpu).max()) < F64_TOL
+    du = np.abs(O.quantize(gpu).astype(int) - O.quantize(cpu).astype(int)).max(axis=2)
+    assert (du <= 1).mean() >= 0.999 and (du == 0).mean() >= 0.999
+    return gpu
+
+
+def test_library_is_the_hip_one():
+    assert R.device_count() >= 1
+
+
+@pytest.mark.parametrize("name", IMAGES)
+def test_golden_png_full_size(name):
+    """The reference's regression set at its own settings (800x800, depth 4, ss 1) against its own PNGs."""
+    rs = Y.load_scene(scene_path("images", name), depth=4, supersampling_level=1)
+    gpu, st = R.render(rs.builder.flatten(), rs.camera, rs.options())
+    assert st["overflow_pixels"] == 0
+    ref = np.array(Image.open(os.path.join(GOLDEN, "renders", "test", name + ".png")).convert("RGB"))
+    diff = np.abs(ref.astype(int) - R.as_u8_rgb(gpu).astype(int)).max(axis=2)
+    assert (diff <= 1).mean() >= 0.999, f"{(diff > 1).sum()} pixels off by more than 1 LSB"
+
+
+@pytest.mark.parametrize("name", IMAGES)
+def test_images_vs_oracle_supersampled(name):
+    rs = Y.load_scene(scene_path("images", name), width=160, height=120, depth=5, supersampling_level=3)
+    check_against_oracle(rs.builder.flatten(), rs.camera, rs.options())
+
+
+@pytest.mark.parametrize("name", ANIMS)
+@pytest.mark.parametrize("time", [0., 0.3])
+def test_animation_frames_vs_oracle(name, time):
+    """AnimationRenderer::render_frame (animation_renderer.rs:61-66): scene.animate(t) then the same hot path."""
+    rs = Y.load_scene(scene_path("animations", "general/" + name), width=128, height=128, depth=8 if name == "csg-lens" else 4)
+    check_against_oracle(rs.builder.flatten(time=time), rs.camera, rs.options())
+
+
+def test_readme_scene_config1():
+    rs = Y.load_scene(os.path.join(os.path.dirname(GOLDEN), "..", "scenes", "readme.yml"), depth=5, supersampling_level=2)
+    check_against_oracle(rs.builder.flatten(), rs.camera, rs.options())
+
+
+@pytest.mark.parametrize("level", [0, 1, 2, 3, 4, 5])
+def test_supersampling_levels(level):
+    rs = Y.load_scene(scene_path("images", "chapters/cylinders"), width=64, height=48, supersampling_level=level)
+    check_against_oracle(rs.builder.flatten(), rs.camera, rs.options())
+
+
+def test_boolean_shadow_mode():
+    rs = Y.load_scene(scene_path("images", "chapters/refractions"), width=96, height=96)
+    check_against_oracle(rs.builder.flatten(), rs.camera, rs.options(shadow_intensity=False))
+
+
+def test_depth_zero_and_max():
+    rs = Y.load_scene(scene_path("images", "chapters/reflections"), width=96, height=96, supersampling_level=1)
+    flat = rs.builder.flatten()
+    for depth in (0, 1, N.RT_MAX_DEPTH):
+        check_against_oracle(flat, rs.camera, S.make_options(1, depth, True))
+    with pytest.raises(R.RtError) as e:
+        R.render(flat, rs.camera, S.make_options(1, N.RT_MAX_DEPTH + 1, True))
+    assert e.value.code == -2
+
+
+def test_ragged_image_sizes():
+    rs = Y.load_scene(scene_path("images", "chapters/making-scene"), width=37, height=21, supersampling_level=2)
+    check_against_oracle(rs.builder.flatten(), rs.camera, rs.options())
+    rs = Y.load_scene(scene_path("images", "chapters/making-scene"), width=1, height=1, supersampling_level=1)
+    check_against_oracle(rs.builder.flatten(), rs.camera, rs.options())
+
+
+def test_empty_scene_and_no_lights():
+    sb = S.SceneBuilder()
+    cam = S.make_camera(16, 16, 1.0)
+    gpu, _ = R.render(sb.flatten(), cam, S.make_options(1, 4, True))
+    assert np.array_equal(gpu, np.zeros((16, 16, 3)))
+    sb = default_testing_builder(light=None)  # zero lights: everything black (integrator.rs:199-228 folds over lights)
+    gpu, _ = R.render(sb.flatten(), S.make_camera(16, 16, 1.0, S.view_transformation((0, 0, -5), (0, 0, 0), (0, 1, 0))),
+                      S.make_options(1, 4, True))
+    assert np.array_equal(gpu, np.zeros((16, 16, 3)))
+
+
+def test_invalid_arguments_fail_loudly():
+    sb = default_testing_builder()
+    flat = sb.flatten()
+    cam = S.make_camera(8, 8, 1.0)
+    opt = S.make_options(1, 4, True)
+    opt.n_offsets = 9
+    with pytest.raises(R.RtError):
+        R.render(flat, cam, opt)
+    L = N.core_lib()
+    assert L.rt_render(None, C.byref(cam), C.byref(S.make_options()), None, None) < 0
+    assert b"required" in L.rt_last_error() or len(L.rt_last_error()) > 0
+
+
+def test_group_as_csg_operand_is_rejected():
+    sb = S.SceneBuilder()
+    g = sb.group([sb.primitive(N.SPHERE)])
+    sb.add_object(sb.csg(N.CSG_UNION, g, sb.primitive(N.CUBE)))
+    with pytest.raises(R.RtError) as e:
+        R.DeviceScene(sb.flatten())
+    assert e.value.code == -2
+
+
+# ---- the reference's unit-test rays through the device path (rt_trace_rays) ---------------------------
+REFLECT_RAY = ((0., 0., -3.), (0., -FRAC_1_SQRT_2, FRAC_1_SQRT_2))
+
+
+def test_known_answer_rays_on_device():
+    opt = options_for_tests()
+    cases = []
+    cases.append((default_testing_builder(), (0, 0, -5), (0, 0, 1), (0.38066, 0.47583, 0.2855)))            # integrator.rs:328
+    cases.append((default_testing_builder(light=((0., 0.25, 0.), (1., 1., 1.))), (0, 0, 0), (0, 0, 1), (0.90498,) * 3))  # :337
+    cases.append((default_testing_builder(), (0, 0, -5), (0, 1, 0), (0., 0., 0.)))                          # :351
+    plane = (N.PLANE, S.Material(reflectivity=0.5), translation(0., -1., 0.))
+    cases.append((default_testing_builder(extra=[plane]), *REFLECT_RAY, (0.87677, 0.92436, 0.82918)))       # :421
+    ball = (N.SPHERE, S.Material(S.Pattern(N.P_CONST, (1., 0., 0.)), ambient=0.5), translation(0., -3.5, -0.5))
+    floor = (N.PLANE, S.Material(transparency=0.5, refractive_index=1.5), translation(0., -1., 0.))
+    cases.append((default_testing_builder(extra=[floor, ball]), *REFLECT_RAY, (0.93642, 0.68642, 0.68642)))  # :591
+    floor = (N.PLANE, S.Material(transparency=0.5, reflectivity=0.5, refractive_index=1.5), translation(0., -1., 0.))
+    cases.append((default_testing_builder(extra=[floor, ball]), *REFLECT_RAY, (0.93391, 0.69643, 0.69243)))  # :630
+    for sb, o, d, want in cases:
+        flat = sb.flatten(build_bvh=False)
+        got = R.DeviceScene(flat).trace_rays(opt, [o], [d])[0]
+        assert np.allclose(got, want, atol=1e-4)
+        assert np.allclose(got, O.color_at(flat, opt, o, d), atol=F64_TOL)
+
+
+def test_random_rays_all_shapes_vs_oracle():
+    """Seeded random rays against a scene holding every shape, a CSG and nested transparent containers."""
+    rs = Y.load_scene(scene_path("images", "chapters/cylinders"))
+    sb = rs.builder
+    glass = S.Material.glass()
+    sb.add_object(sb.csg(N.CSG_DIFFERENCE, sb.primitive(N.CUBE, glass, translation(3., 1., 2.)),
+                         sb.primitive(N.SPHERE, glass, translation(3., 1.5, 1.5))))
+    sb.add_object(sb.primitive(N.SMOOTH_TRIANGLE, None, None, tri=[-3., 0., 2., -2., 2., 2., -1., 0., 2., -1., 0., -1., 0., 1., -1., 1., 0., -1.]))
+    sb.add_object(sb.primitive(N.TRIANGLE, S.Material(reflectivity=0.3), None, tri=[-3., 0., 3., -2., 2., 3., -1., 0., 3.]))
+    flat = sb.flatten()
+    rng = np.random.default_rng(1234)
+    n = 4096
+    origins = rng.uniform(-6, 6, (n, 3)) * [1., 0.5, 1.] + [0., 3., 0.]
+    targets = rng.uniform(-3, 3, (n, 3)) + [0., 1., 0.]
+    dirs = targets - origins
+    dirs /= np.linalg.norm(dirs, axis=1, keepdims=True)
+    opt = S.make_options(1, 5, True)
+    got = R.DeviceScene(flat).trace_rays(opt, origins, dirs)
+    want = np.stack([O.color_at(flat, opt, o, d) for o, d in zip(origins, dirs)])
+    assert float(np.abs(got - want).max()) < F64_TOL
+    assert (np.abs(got - want).max(axis=1) == 0).mean() > 0.9
+
+
+# ---- properties at full size -------------------------------------------------------------------------
+def _torch():
+    import torch
+    return torch
+
+
+def test_tile_partition_equals_whole_image_full_size():
+    """dragons.yml 800x800 (config 2): 3 cyclic tile parts, gathered and assembled on device, equal the one-launch image
+    bit for bit; rendering twice is idempotent."""
+    torch = _torch()
+    rs = Y.load_scene(scene_path("images", "general/dragons"), depth=5, supersampling_level=2)
+    cam, opt = rs.camera, rs.options()
+    scene = R.DeviceScene(rs.builder.flatten())
+    w, h = cam.width, cam.height
+    whole = torch.empty((h, w, 3), dtype=torch.float64, device="cuda")
+    scene.render_device(cam, opt, whole.data_ptr())
+    again = torch.empty_like(whole)
+    scene.render_device(cam, opt, again.data_ptr())
+    torch.cuda.synchronize()
+    assert torch.equal(whole, again)
+    n_parts = 3
+    n_max = D.tile_count(w, h, 0, n_parts)
+    bufs = torch.zeros((n_parts, n_max * 64 * 3), dtype=torch.float64, device="cuda")
+    for p in range(n_parts):
+        scene.render_tiles(cam, opt, p, n_parts, bufs[p].data_ptr())
+    out = torch.empty_like(whole)
+    R.assemble_tiles(w, h, n_parts, n_max, bufs.data_ptr(), out.data_ptr())
+    torch.cuda.synchronize()
+    assert torch.equal(out, whole)
+    # host mirror of the assembly agrees with the device kernel
+    parts = [bufs[p].cpu().numpy().reshape(n_max, 64, 3) for p in range(n_parts)]
+    assert np.array_equal(D.assemble_tiles_host(w, h, parts), whole.cpu().numpy())
+    # tight (unpadded) concatenation
+    tight = torch.cat([bufs[p][: D.tile_count(w, h, p, n_parts) * 192] for p in range(n_parts)])
+    out2 = torch.empty_like(whole)
+    R.assemble_tiles(w, h, n_parts, 0, tight.data_ptr(), out2.data_ptr())
+    torch.cuda.synchronize()
+    assert torch.equal(out2, whole)
+
+
+def test_supersample_is_mean_of_offset_renders():
+    """color_at_pixel sums the n^2 samples left to right and divides (renderer.rs:57-65): reproduce the ss-2 image from
+    four single-sample renders with the offsets applied by hand, in the same order, on the host."""
+    rs = Y.load_scene(scene_path("images", "chapters/cubes"), width=200, height=200)
+    flat = rs.builder.flatten()
+    cam = rs.camera
+    ss2, _ = R.render(flat, cam, S.make_options(2, 4, True))
+    acc = np.zeros_like(ss2)
+    for dx in (-0.25, 0.25):
+        for dy in (-0.25, 0.25):
+            o = S.make_options(1, 4, True)
+            o.n_offsets = 1
+            # a one-sample render at offset (dx, dy): shift via the option's single offset only works when dx == dy,
+            # so use the ray entry point instead
+            xs, ys = np.meshgrid(np.arange(cam.width, dtype=np.float64), np.arange(cam.height, dtype=np.float64))
+            rays = [O.ray_for_pixel(cam, x + dx, y + dy) for x, y in zip(xs.ravel(), ys.ravel())]
+            col = R.DeviceScene(flat).trace_rays(S.make_options(1, 4, True), [r[0] for r in rays], [r[1] for r in rays])
+            acc = acc + col.reshape(cam.height, cam.width, 3)
+    assert np.array_equal(acc / 4.0, ss2)
+
+
+def test_quantize_device_matches_host():
+    torch = _torch()
+    rng = np.random.default_rng(7)
+    v = rng.uniform(-0.2, 1.2, 100000)
+    v[:6] = [1.5, 0.5, -1.5, float("nan"), 0.5 / 255., 254.5 / 255.]
+    d = torch.from_numpy(v).cuda()
+    out = torch.empty(v.size, dtype=torch.uint8, device="cuda")
+    R.quantize_device(d.data_ptr(), v.size, out.data_ptr())
+    torch.cuda.synchronize()
+    got = out.cpu().numpy()
+    assert np.array_equal(got, O.quantize(v)) and np.array_equal(got, R.as_u8_rgb(v))
+    assert list(got[:4]) == [255, 128, 0, 0]
