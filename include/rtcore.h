@@ -170,6 +170,8 @@ typedef struct rt_options {
 typedef struct rt_stats {
   uint64_t rays_primary, rays_shadow, rays_reflect, rays_refract;
   uint64_t node_visits, tri_tests, prim_tests;
+  uint64_t hits;      /* shaded hits (one IntersecComputations each) */
+  uint64_t hit_bytes; /* algorithmic bytes of those hits: normals/inverse + material (+ pattern) + lights, SURVEY.md §8d */
   uint64_t overflow_pixels;
   double ms_upload, ms_kernel, ms_download;
 } rt_stats;

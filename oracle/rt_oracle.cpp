@@ -80,8 +80,9 @@ struct Inter {  // intersection.rs:137-143
 
 struct Counters {
   uint64_t rays_primary = 0, rays_shadow = 0, rays_reflect = 0, rays_refract = 0;
-  uint64_t node_visits = 0, tri_tests = 0, prim_tests = 0;
+  uint64_t node_visits = 0, tri_tests = 0, prim_tests = 0, hits = 0, hit_bytes = 0;
   void add(const Counters& o) {
+    hits += o.hits; hit_bytes += o.hit_bytes;
     rays_primary += o.rays_primary; rays_shadow += o.rays_shadow; rays_reflect += o.rays_reflect;
     rays_refract += o.rays_refract; node_visits += o.node_visits; tri_tests += o.tri_tests; prim_tests += o.prim_tests;
   }
@@ -629,6 +630,16 @@ bool hit_comps(const Ctx& cx, const Ray& ray, Comps& out) {
   double n1, n2;
   get_refractive(cx, col.vec, col.hit, n1, n2);
   out = make_comps(cx, col.hit, ray, n1, n2);
+  {  // algorithmic bytes of shading this hit
+    const rt_scene_desc* s = cx.s;
+    uint32_t p = col.hit.prim;
+    uint64_t b = 64u + 48u * s->n_lights;
+    uint8_t sh = s->prim_shape[p];
+    b += sh == RT_SHAPE_SMOOTH_TRIANGLE ? 72u : (sh == RT_SHAPE_TRIANGLE ? 24u : (s->prim_xform[p] != RT_NONE ? 96u : 0u));
+    if (s->pattern_kind[s->prim_material[p]] != RT_PATTERN_CONST) b += 144u;
+    cx.c->hits++;
+    cx.c->hit_bytes += b;
+  }
   return true;
 }
 
@@ -703,6 +714,8 @@ int rto_render_region(const rt_scene_desc* scene, const rt_camera* cam, const rt
     stats->node_visits = total.node_visits;
     stats->tri_tests = total.tri_tests;
     stats->prim_tests = total.prim_tests;
+    stats->hits = total.hits;
+    stats->hit_bytes = total.hit_bytes;
   }
   return RT_OK;
 }

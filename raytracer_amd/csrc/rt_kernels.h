@@ -16,7 +16,7 @@
 enum { MODE_CLOSEST = 0, MODE_SHADOW = 1 };
 
 struct Counters {
-  uint32_t rays_primary, rays_shadow, rays_reflect, rays_refract, node_visits, tri_tests, prim_tests, overflow;
+  uint32_t rays_primary, rays_shadow, rays_reflect, rays_refract, node_visits, tri_tests, prim_tests, hits, hit_bytes, overflow;
 };
 
 // Closest-hit / shadow collector: IntersectionCollector (src/render/ray/intersection.rs:17-135) without the Vec.
@@ -678,6 +678,13 @@ __device__ d3 trace(const DevScene& s, const DevOptions& opt, d3 ro, d3 rd, Coun
         F.n1 = n1;
         F.n2 = n2;
         F.rr = F.rg = F.rb = 0.;
+        if (STATS) {  // algorithmic bytes of shading this hit
+          cnt.hits++;
+          uint32_t b = 64u + 48u * s.n_lights;
+          b += info.x == RT_SHAPE_SMOOTH_TRIANGLE ? 72u : (info.x == RT_SHAPE_TRIANGLE ? 24u : (info.z != RT_NONE ? 96u : 0u));
+          if (s.pattern_kind[info.y] != RT_PATTERN_CONST) b += 144u;
+          cnt.hit_bytes += b;
+        }
         // reflected_color_at_depth (integrator.rs:154-168)
         if ((uint32_t)depth < opt.max_depth && !approx_eq(mat[RT_MAT_REFLECTIVITY], 0.)) {
           HitGeom g = hit_geom(s, info, o, d, F.t, F.u, F.v);

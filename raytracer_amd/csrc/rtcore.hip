@@ -15,14 +15,15 @@
 // ---------------------------------------------------------------------------------------------
 // kernels
 // ---------------------------------------------------------------------------------------------
-#define RT_N_COUNTERS 8
+#define RT_N_COUNTERS 10
 
 template <bool STATS>
 __device__ __forceinline__ void flush_counters(const Counters& c, unsigned long long* stats, uint32_t* overflow_flag) {
   if (c.overflow) atomicOr(overflow_flag, 1u);
   if (!STATS) return;
   uint32_t v[RT_N_COUNTERS] = {c.rays_primary, c.rays_shadow, c.rays_reflect, c.rays_refract,
-                               c.node_visits,  c.tri_tests,   c.prim_tests,   c.overflow};
+                               c.node_visits,  c.tri_tests,   c.prim_tests,   c.hits,
+                               c.hit_bytes,    c.overflow};
   for (int k = 0; k < RT_N_COUNTERS; k++) {
     unsigned long long x = v[k];
     for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
@@ -50,7 +51,7 @@ __global__ __launch_bounds__(64) void render_tiles_kernel(DevScene s, rt_camera 
   uint32_t lane = threadIdx.x;
   uint32_t px = (tile % tiles_x) * RT_TILE_DIM + (lane & 7u);
   uint32_t py = (tile / tiles_x) * RT_TILE_DIM + (lane >> 3);
-  Counters cnt = {0, 0, 0, 0, 0, 0, 0, 0};
+  Counters cnt = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   bool inside = px < cam.width && py < cam.height;
   d3 color = mk3(0., 0., 0.);
   if (inside) {
@@ -119,7 +120,7 @@ __global__ __launch_bounds__(64) void trace_rays_kernel(DevScene s, DevOptions o
                                                         const double* __restrict__ dir, double* __restrict__ out,
                                                         uint32_t* overflow_flag) {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  Counters cnt = {0, 0, 0, 0, 0, 0, 0, 0};
+  Counters cnt = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   if (i < n) {
     d3 o = mk3(origin[3 * i], origin[3 * i + 1], origin[3 * i + 2]);
     d3 d = mk3(dir[3 * i], dir[3 * i + 1], dir[3 * i + 2]);
@@ -331,7 +332,9 @@ int launch_render(const rt_scene* scene, const rt_camera* cam, const rt_options*
     stats->node_visits = h[4];
     stats->tri_tests = h[5];
     stats->prim_tests = h[6];
-    stats->overflow_pixels = h[7];
+    stats->hits = h[7];
+    stats->hit_bytes = h[8];
+    stats->overflow_pixels = h[9];
     stats->ms_kernel = ms;
     if (ovf) return fail(RT_ERR_OVERFLOW, "a per-ray bounded list (BVH stack or CSG hit list) overflowed on the device");
   }
