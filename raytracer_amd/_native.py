@@ -75,6 +75,8 @@ class rts_material(C.Structure):
 
 def _load(name: str) -> C.CDLL:
     path = os.path.join(LIB_DIR, name)
+    if name == "librtcore.so" and os.environ.get("RTCORE_LIB"):  # development: A/B a differently built render core
+        path = os.environ["RTCORE_LIB"]
     if not os.path.exists(path):
         raise RuntimeError(
             f"{path} is missing: build the native libraries first (python -c 'import __graft_entry__ as g; g.build()')")

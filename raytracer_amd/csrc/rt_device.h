@@ -63,9 +63,11 @@ struct __attribute__((aligned(16))) DevEntry {
   double bb[6];    // bounding box of the child when it is a group (bounding_box.rs:25-28)
   uint32_t ref;    // RT_MAKE_REF(kind, index)
   uint32_t begin;  // group child: first record of ITS children
-  uint32_t count;  // group child: number of children
+  uint32_t count;  // group child: number of children, | RT_NODE_INNER2 when it has exactly two children, both groups
   uint32_t pad;
 };
+#define RT_NODE_INNER2 0x80000000u
+#define RT_NODE_COUNT_MASK 0x0FFFFFFFu
 
 struct DevScene {
   const DevEntry* entries;

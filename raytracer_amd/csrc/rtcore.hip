@@ -16,6 +16,9 @@
 // kernels
 // ---------------------------------------------------------------------------------------------
 #define RT_N_COUNTERS 10
+#ifndef RT_WAVES_PER_EU
+#define RT_WAVES_PER_EU 1  // minimum waves per SIMD the register allocator must leave room for
+#endif
 
 template <bool STATS>
 __device__ __forceinline__ void flush_counters(const Counters& c, unsigned long long* stats, uint32_t* overflow_flag) {
@@ -42,7 +45,7 @@ __device__ __forceinline__ uint32_t xcd_remap(uint32_t bid, uint32_t n) {
 
 // Renderer::color_at_pixel (renderer.rs:50-66) for one 8x8 tile per wavefront.
 template <bool STATS>
-__global__ __launch_bounds__(64) void render_tiles_kernel(DevScene s, rt_camera cam, DevOptions opt, uint32_t part,
+__global__ __launch_bounds__(64, RT_WAVES_PER_EU) void render_tiles_kernel(DevScene s, rt_camera cam, DevOptions opt, uint32_t part,
                                                           uint32_t n_parts, uint32_t tiles_x, uint32_t n_owned, int packed,
                                                           double* __restrict__ out, unsigned long long* stats,
                                                           uint32_t* overflow_flag) {
@@ -116,7 +119,7 @@ __global__ __launch_bounds__(256) void quantize_kernel(const double* __restrict_
 }
 
 // Integrator::color_at for arbitrary rays (one lane per ray)
-__global__ __launch_bounds__(64) void trace_rays_kernel(DevScene s, DevOptions opt, uint32_t n, const double* __restrict__ origin,
+__global__ __launch_bounds__(64, RT_WAVES_PER_EU) void trace_rays_kernel(DevScene s, DevOptions opt, uint32_t n, const double* __restrict__ origin,
                                                         const double* __restrict__ dir, double* __restrict__ out,
                                                         uint32_t* overflow_flag) {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
