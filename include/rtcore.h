@@ -162,6 +162,9 @@ typedef struct rt_options {
   double offsets[5];
   uint32_t max_depth;        /* max_recursive_depth; device limit RT_MAX_DEPTH */
   uint32_t shadow_intensity; /* 1: production (intensity sums); 0: boolean shadows of the unit tests */
+  uint32_t reference_order;  /* 0: production traversal (near child first, LDS stack).  1: visit the BVH exactly in the
+                                order of ObjectGroup::intersect_iter (group.rs:171-201): validation and counting mode —
+                                same pixels, slower; its node/triangle counts are the reference's algorithmic work */
 } rt_options;
 
 #define RT_MAX_DEPTH 16u
@@ -173,6 +176,8 @@ typedef struct rt_stats {
   uint64_t hits;      /* shaded hits (one IntersecComputations each) */
   uint64_t hit_bytes; /* algorithmic bytes of those hits: normals/inverse + material (+ pattern) + lights, SURVEY.md §8d */
   uint64_t overflow_pixels;
+  uint64_t wave_steps;  /* production traversal only: wavefront-level traversal steps ... */
+  uint64_t lane_steps;  /* ... and the lanes active in them (lane_steps / (64 * wave_steps) = SIMD utilisation) */
   double ms_upload, ms_kernel, ms_download;
 } rt_stats;
 

@@ -53,28 +53,56 @@ __device__ __forceinline__ d3 mat_transposed_vector(const double* __restrict__ m
 }
 
 // ---------------------------------------------------------------------------------------------
-// Device scene layout (built by rt_scene_create from rt_scene_desc)
+// Device scene layout (built by rt_scene_create from rt_scene_desc; see DESIGN.md "Data layout in HBM")
 // ---------------------------------------------------------------------------------------------
 
-// One record per child reference, 64 B, 16-B aligned: a node visit reads its children's records
-// contiguously (reverse order), and a group child's bounding box and child range come with its record,
-// so descending costs no extra dependent load.  Record 0 is the scene root.
+// --- fast path (rt_fast.h): binary nodes, 128 B, one dependent load per traversal step -----------
+// A node holds the boxes of BOTH children, so testing the two children of a node is one 128-B fetch and the
+// child references come with it.  Groups of the reference that are not "two sub-groups" are rewritten at scene
+// creation: a group of primitives becomes a LEAF reference in its parent (no node of its own); n-ary or mixed
+// groups become short chains of binary nodes whose synthetic boxes repeat the group's own box.
+#define RT_FREF_INNER 0u  // index = node
+#define RT_FREF_TRIS 1u   // index = first triangle of a run in tri_isect/tri_norm, count = run length
+#define RT_FREF_PRIMS 2u  // index = first entry of a run in leaf_ref (RT_REF_PRIM / RT_REF_CSG references)
+#define RT_FREF_EMPTY 3u
+#define RT_FREF_KIND_SHIFT 30u
+#define RT_FREF_COUNT_SHIFT 24u
+#define RT_FREF_COUNT_MASK 0x3Fu
+#define RT_FREF_INDEX_MASK 0x00FFFFFFu
+#define RT_FREF_LEAF_MAX 63u
+#define RT_FREF_NONE 0xFFFFFFFFu  // kind EMPTY: nothing left to visit
+#define RT_MAKE_FREF(kind, count, index) (((uint32_t)(kind) << RT_FREF_KIND_SHIFT) | ((uint32_t)(count) << RT_FREF_COUNT_SHIFT) | (uint32_t)(index))
+
+struct __attribute__((aligned(128))) DevNode {
+  double bb[2][6];  // boxes of child 0 and child 1: min x,y,z, max x,y,z (bounding_box.rs:25-28), exact f64
+  uint32_t ref[2];  // RT_MAKE_FREF
+  uint32_t pad[2];
+};
+
+// Triangles are stored in leaf order, RT_TRI_STRIDE doubles each (80 B, 16-B aligned): p1, e1, e2, then the
+// primitive index in the low 32 bits of the tenth slot.
+#define RT_TRI_STRIDE 10
+
+// --- reference-order path (rt_reforder.h): one record per child reference of the input tree -------
+// 64 B, 16-B aligned: a node visit reads its children's records contiguously; a group child's bounding box and
+// child range come with its record.  Record 0 is the scene root.
 struct __attribute__((aligned(16))) DevEntry {
   double bb[6];    // bounding box of the child when it is a group (bounding_box.rs:25-28)
   uint32_t ref;    // RT_MAKE_REF(kind, index)
   uint32_t begin;  // group child: first record of ITS children
-  uint32_t count;  // group child: number of children, | RT_NODE_INNER2 when it has exactly two children, both groups
+  uint32_t count;  // group child: number of children
   uint32_t pad;
 };
-#define RT_NODE_INNER2 0x80000000u
-#define RT_NODE_COUNT_MASK 0x0FFFFFFFu
 
 struct DevScene {
-  const DevEntry* entries;
-  const uint4* prim_info;  // x shape, y material, z xform (RT_NONE = none), w geom
+  const DevNode* nodes;       // fast path; node 0 is a synthetic root whose child 0 is the scene's root group
+  const uint32_t* leaf_ref;   // fast path: primitive / CSG references of PRIMS leaves
+  const uint32_t* prim_rank;  // visit order of each primitive in ObjectGroup::intersect_iter (decides ties in t)
+  const DevEntry* entries;    // reference-order path
+  const uint4* prim_info;     // x shape, y material, z xform (RT_NONE = none), w geom (triangles: index in leaf order)
   const uint32_t* prim_csg_left;
   const double* xform_inv;  // [n][16]
-  const double* tri_isect;  // [n][9]  p1, e1, e2
+  const double* tri_isect;  // [n][RT_TRI_STRIDE]  p1, e1, e2, prim
   const double* tri_norm;   // [n][9]  n1, n2, n3
   const double* quadric;    // [n][2]  y_min, y_max
   const uint8_t* quadric_closed;

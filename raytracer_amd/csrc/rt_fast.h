@@ -1,0 +1,547 @@
+// rt_fast.h — the per-pixel render core as gfx950 device code (the path that ships and is benchmarked).
+//
+// One wavefront (64 lanes) renders one 8x8 pixel tile; each lane owns one pixel and runs the whole
+// Renderer::color_at_pixel (src/render/renderer.rs:50-66) for it.
+//
+//  * The reflect/refract recursion of Integrator::shade_hit_at_depth (src/shading/integrator.rs:199-228) is a
+//    per-lane state machine over an explicit frame stack (post-order, so every sum is formed in the reference's
+//    order).  EVERY ray of the machine — primary, reflected, refracted, shadow, and the refractive-container walk —
+//    goes through ONE traversal loop, so lanes that are at different points of the recursion still traverse together.
+//  * Traversal is a while-while loop over 128-B binary nodes (both child boxes per fetch), near child first, with the
+//    per-lane stack in LDS (RT_LDS_STACK entries, deeper entries spill to scratch).  The far child is pushed with its
+//    entry time rounded down to f32 and dropped at pop time once the closest hit is nearer.
+//  * What makes a different visiting order legal: the closest hit of the reference is "smallest t, first visited wins
+//    ties" (intersection.rs:65-77, strict <).  The visit order of ObjectGroup::intersect_iter (group.rs:171-201) is a
+//    fixed pre-order of the tree, so "first visited" = smallest prim_rank, which is what ties are resolved with here.
+//    Boxes are culled only when no accepted intersection can lie inside them (t_enter > closest t, or box entirely
+//    behind the origin), so the set of candidate intersections is the reference's.  Negative-t intersections, which
+//    the reference collects on the same walk for the refractive-index containers (intersection.rs:258-302), are
+//    collected by a second walk over the boxes behind the origin, and only when the hit is transparent.
+#pragma once
+#include "rt_shading.h"
+
+namespace fast {
+
+#define RT_LDS_STACK 16                                   // per-lane stack entries in LDS (8 KB per wavefront)
+#define RT_OVF_STACK 48                                   // further entries in scratch
+#define RT_FAST_STACK_MAX (RT_LDS_STACK + RT_OVF_STACK)  // validated against the tree depth at scene creation
+#define RT_FRAMES (RT_MAX_DEPTH + 1)
+
+enum { M_CLOSEST = 0, M_SHADOW = 1, M_CONTAINERS = 2 };
+
+// The ray being traversed and its collector (IntersectionCollector, intersection.rs:17-135, without the Vec).
+struct Trav {
+  d3 o, d, dinv;
+  double limit;   // closest: t of the best hit so far; shadow: distance to the light; containers: 0 (only boxes entered at t <= 0)
+  double a, b;    // closest: u, v of the hit; shadow: a = accumulated intensity; containers: largest negative t of the two innermost containers
+  uint32_t p, q;  // closest: p = hit primitive; containers: the two innermost containers
+  uint32_t h;     // containers: the primitive that was hit (closest pass)
+  uint32_t flag;  // containers: the hit primitive has an odd number of negative-t intersections
+  uint32_t mode;
+  uint32_t cur;   // reference being visited, RT_FREF_NONE when the traversal is complete
+  int sp;
+};
+
+__device__ __forceinline__ void trav_start(Trav& T, d3 o, d3 d, uint32_t mode, double limit) {
+  T.o = o;
+  T.d = d;
+  T.dinv = mk3(1. / d.x, 1. / d.y, 1. / d.z);  // Ray::new (ray.rs:27-34)
+  T.limit = limit;
+  T.mode = mode;
+  T.cur = RT_MAKE_FREF(RT_FREF_INNER, 0, 0);
+  T.sp = 0;
+  if (mode == M_CLOSEST) {
+    T.p = RT_NONE;
+    T.a = T.b = -INFINITY;
+  } else if (mode == M_SHADOW) {
+    T.a = 0.;
+  } else {
+    T.a = T.b = -INFINITY;
+    T.p = T.q = RT_NONE;
+    T.flag = 0;
+  }
+}
+
+// All roots of ONE primitive, in the order the reference add()s them (intersection.rs:65-109).
+template <bool STATS>
+__device__ __forceinline__ void add_roots(const DevScene& s, Trav& T, uint32_t prim, uint32_t material, int n, const double* ts,
+                                          double u, double v) {
+  if (T.mode == M_CLOSEST) {
+    for (int i = 0; i < n; i++) {
+      double t = ts[i];
+      if (!sign_positive(t)) continue;
+      bool take = t < T.limit;
+      if (!take && t == T.limit && T.p != RT_NONE && T.p != prim) take = s.prim_rank[prim] < s.prim_rank[T.p];
+      if (take) {
+        T.limit = t;
+        T.p = prim;
+        T.a = u;
+        T.b = v;
+      }
+    }
+  } else if (T.mode == M_SHADOW) {
+    double transparency = 0.;
+    bool loaded = false;
+    for (int i = 0; i < n; i++) {
+      double t = ts[i];
+      if (sign_positive(t) && !approx_eq(t, T.limit) && t < T.limit && T.a < 1.) {  // intersection.rs:78-87
+        if (!loaded) {
+          transparency = s.material[(size_t)material * RT_MAT_STRIDE + RT_MAT_TRANSPARENCY];
+          loaded = true;
+        }
+        T.a += 1. - transparency;
+      }
+    }
+  } else {
+    int neg = 0;
+    double maxneg = -INFINITY;
+    for (int i = 0; i < n; i++) {
+      double t = ts[i];
+      if (!sign_positive(t)) {
+        neg++;
+        maxneg = fmax(maxneg, t);
+      }
+    }
+    if (neg & 1) {
+      // innermost containers = odd-count objects with the largest negative t; among equal t the one the reference
+      // visits later sorts later (stable sort of the collector's vec), i.e. the larger rank
+      uint32_t r = s.prim_rank[prim];
+      bool over_a = maxneg > T.a || (maxneg == T.a && (T.p == RT_NONE || r >= s.prim_rank[T.p]));
+      if (over_a) {
+        T.b = T.a;
+        T.q = T.p;
+        T.a = maxneg;
+        T.p = prim;
+      } else {
+        bool over_b = maxneg > T.b || (maxneg == T.b && (T.q == RT_NONE || r >= s.prim_rank[T.q]));
+        if (over_b) {
+          T.b = maxneg;
+          T.q = prim;
+        }
+      }
+    }
+    if (prim == T.h) T.flag = (uint32_t)(neg & 1);
+  }
+}
+
+// CsgObject::intersect (csg.rs:112-122): survivors go to the collector in ascending t.
+template <bool STATS>
+__device__ __forceinline__ void add_csg(const DevScene& s, Trav& T, uint32_t csg_root, Counters& cnt) {
+  CsgHit list[RT_CSG_LIST_MAX];
+  int n = csg_survivors<STATS>(s, csg_root, T.o, T.d, T.dinv, list, cnt);
+  if (T.mode == M_CONTAINERS) {
+    // negative-t survivors, aggregated per leaf object (they all come from this one call)
+    for (int i = 0; i < n; i++) {
+      if (sign_positive(list[i].t)) continue;
+      bool first = true;
+      for (int j = 0; j < i; j++)
+        if (!sign_positive(list[j].t) && list[j].prim == list[i].prim) first = false;
+      if (!first) continue;
+      double ts[RT_CSG_LIST_MAX];
+      int k = 0;
+      for (int j = i; j < n; j++)
+        if (!sign_positive(list[j].t) && list[j].prim == list[i].prim) ts[k++] = list[j].t;
+      add_roots<STATS>(s, T, list[i].prim, 0, k, ts, 0., 0.);
+    }
+  } else {
+    for (int i = 0; i < n; i++) {
+      uint32_t prim = list[i].prim;
+      uint32_t material = T.mode == M_SHADOW ? s.prim_info[prim].y : 0u;
+      add_roots<STATS>(s, T, prim, material, 1, &list[i].t, list[i].u, list[i].v);
+    }
+  }
+}
+
+// BoundingBox::intersection_time (bounding_box.rs:192-225) + the exit time.  NaN (0 * inf) is dropped by fmax/fmin like
+// f64::max/min; the reference's early return after x,y is implied by the final test.
+__device__ __forceinline__ bool box_times(const double* __restrict__ bb, d3 o, d3 dinv, double& tmin, double& tmax) {
+  double xmin, xmax, ymin, ymax, zmin, zmax;
+  axis_times(o.x, dinv.x, bb[0], bb[3], xmin, xmax);
+  axis_times(o.y, dinv.y, bb[1], bb[4], ymin, ymax);
+  axis_times(o.z, dinv.z, bb[2], bb[5], zmin, zmax);
+  tmin = fmax(fmax(xmin, ymin), zmin);
+  tmax = fmin(fmin(xmax, ymax), zmax);
+  return !(tmin > tmax);
+}
+
+__device__ __forceinline__ void stack_push(Trav& T, uint2* lds, uint2* ovf, uint32_t ref, double t, Counters& cnt) {
+  uint2 e = make_uint2(ref, __float_as_uint(__double2float_rd(t)));
+  if (T.sp < RT_LDS_STACK) lds[T.sp * 64] = e;
+  else if (T.sp < RT_FAST_STACK_MAX) ovf[T.sp - RT_LDS_STACK] = e;
+  else {
+    cnt.overflow = 1;
+    return;
+  }
+  T.sp++;
+}
+
+__device__ __forceinline__ uint32_t stack_pop(Trav& T, const uint2* lds, const uint2* ovf) {
+  while (T.sp > 0) {
+    T.sp--;
+    uint2 e = lds[(T.sp < RT_LDS_STACK ? T.sp : RT_LDS_STACK - 1) * 64];
+    if (T.sp >= RT_LDS_STACK) e = ovf[T.sp - RT_LDS_STACK];
+    if (!((double)__uint_as_float(e.y) > T.limit)) return e.x;  // still able to hold an accepted intersection
+  }
+  return RT_FREF_NONE;
+}
+
+__device__ __forceinline__ void count_step(Counters& cnt) {  // statistics builds only
+  unsigned long long active = __builtin_amdgcn_ballot_w64(true);
+  cnt.lane_steps++;
+  if ((uint32_t)(__ffsll((long long)active) - 1) == (threadIdx.x & 63u)) cnt.wave_steps++;
+}
+
+// Runs the lane's traversal to completion (lanes whose T.cur is RT_FREF_NONE have nothing to do).
+template <bool STATS>
+__device__ __forceinline__ void trav_run(const DevScene& s, Trav& T, uint2* lds, Counters& cnt) {
+  uint2 ovf[RT_OVF_STACK];
+  while (T.cur != RT_FREF_NONE) {
+    // ---- inner nodes: descend until this lane holds a leaf (or runs out of work) ----
+    while ((T.cur >> RT_FREF_KIND_SHIFT) == RT_FREF_INNER) {
+      if (STATS) count_step(cnt);
+      const DevNode* node = s.nodes + (T.cur & RT_FREF_INDEX_MASK);
+      double bb0[6], bb1[6];
+      for (int k = 0; k < 6; k++) bb0[k] = node->bb[0][k];
+      for (int k = 0; k < 6; k++) bb1[k] = node->bb[1][k];
+      uint32_t r0 = node->ref[0], r1 = node->ref[1];
+      double t0, t1, x0, x1;
+      bool h0 = box_times(bb0, T.o, T.dinv, t0, x0);
+      bool h1 = box_times(bb1, T.o, T.dinv, t1, x1);
+      if (STATS) cnt.node_visits += 1u + (r1 != RT_FREF_NONE ? 1u : 0u);
+      // a box can hold an accepted intersection only if it is entered no later than the limit ...
+      h0 = h0 && !(t0 > T.limit) && r0 != RT_FREF_NONE;
+      h1 = h1 && !(t1 > T.limit) && r1 != RT_FREF_NONE;
+      if (T.mode != M_CONTAINERS) {  // ... and, for t >= 0 intersections, is not entirely behind the origin
+        h0 = h0 && !(x0 < 0.);
+        h1 = h1 && !(x1 < 0.);
+      }
+      if (h0 && h1) {
+        bool swap = t1 < t0;  // near child first
+        stack_push(T, lds, ovf, swap ? r0 : r1, swap ? t0 : t1, cnt);
+        T.cur = swap ? r1 : r0;
+      } else if (h0) {
+        T.cur = r0;
+      } else if (h1) {
+        T.cur = r1;
+      } else {
+        T.cur = stack_pop(T, lds, ovf);
+      }
+    }
+    if (T.cur == RT_FREF_NONE) break;
+    // ---- leaf ----
+    if (STATS) count_step(cnt);
+    uint32_t kind = T.cur >> RT_FREF_KIND_SHIFT;
+    uint32_t count = (T.cur >> RT_FREF_COUNT_SHIFT) & RT_FREF_COUNT_MASK, first = T.cur & RT_FREF_INDEX_MASK;
+    if (kind == RT_FREF_TRIS) {
+      for (uint32_t j = 0; j < count; j++) {
+        const double* tri = s.tri_isect + (size_t)(first + j) * RT_TRI_STRIDE;
+        double t, u, v;
+        if (STATS) cnt.tri_tests++;
+        if (triangle_roots(tri, T.o, T.d, &t, u, v)) {
+          uint32_t prim = (uint32_t)__double_as_longlong(tri[9]);
+          uint32_t material = T.mode == M_SHADOW ? s.prim_info[prim].y : 0u;
+          add_roots<STATS>(s, T, prim, material, 1, &t, u, v);
+        }
+      }
+    } else {  // RT_FREF_PRIMS
+      for (uint32_t j = 0; j < count; j++) {
+        uint32_t ref = s.leaf_ref[first + j];
+        uint32_t idx = ref & RT_REF_INDEX_MASK;
+        if ((ref >> RT_REF_KIND_SHIFT) == RT_REF_PRIM) {
+          uint4 info = s.prim_info[idx];
+          double ts[4], u, v;
+          int n = prim_roots<STATS>(s, info, T.o, T.d, T.dinv, ts, u, v, cnt);
+          if (n) add_roots<STATS>(s, T, idx, info.y, n, ts, u, v);
+        } else {
+          add_csg<STATS>(s, T, idx, cnt);
+        }
+      }
+    }
+    if (T.mode == M_SHADOW && T.a >= 1.) {  // min(intensity, 1) is already 1 (intersection.rs:124-126)
+      T.cur = RT_FREF_NONE;
+      T.sp = 0;
+    } else {
+      T.cur = stack_pop(T, lds, ovf);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Integrator::color_at (integrator.rs:59-70) with the recursion of shade_hit_at_depth (:199-228) as a state machine.
+// ---------------------------------------------------------------------------------------------
+struct Frame {  // one per recursion level, in scratch
+  double t, u, v;  // the hit, kept across the container walk
+  double over[3], under[3], eye[3], normal[3];  // IntersecComputations (intersection.rs:201-215)
+  double n1, n2;
+  double refl[3];  // reflected colour x reflectivity (integrator.rs:154-168)
+  double rr[3];    // reflected + refracted, or their Schlick mix (integrator.rs:213-225)
+  double acc[3];   // the fold over the lights (integrator.rs:201-227)
+  uint32_t prim, pc, light, pad;
+};
+
+enum {
+  PC_TRACE = 0,        // a traversal is pending: leave the machine
+  PC_DONE,             // the lane has no more samples
+  PC_AFTER_CLOSEST,
+  PC_AFTER_CONTAINERS,
+  PC_HIT_READY,
+  PC_AFTER_REFLECT,
+  PC_REFRACT,
+  PC_AFTER_REFRACT,
+  PC_LIGHTS,
+  PC_AFTER_SHADOW,
+  PC_RETURN
+};
+
+__device__ __forceinline__ void st3(double* p, d3 v) { p[0] = v.x; p[1] = v.y; p[2] = v.z; }
+__device__ __forceinline__ d3 ld3(const double* p) { return mk3(p[0], p[1], p[2]); }
+
+// Source of primary rays for one lane.  Camera: the supersampling grid of one pixel (renderer.rs:50-66).
+struct PixelRays {
+  const rt_camera* cam;
+  const DevOptions* opt;
+  double x, y;
+  uint32_t k, n;  // next sample, samples per pixel
+  d3 color;
+  __device__ __forceinline__ bool next(d3& o, d3& d) {
+    if (k >= n) return false;
+    uint32_t i = k / opt->n_offsets, j = k % opt->n_offsets;  // dx outer, dy inner (renderer.rs:57-64)
+    camera_ray(*cam, x + opt->offsets[i], y + opt->offsets[j], o, d);
+    k++;
+    return true;
+  }
+  __device__ __forceinline__ void add(d3 c) { color = add3(color, c); }
+};
+
+// Source of one given ray (rt_trace_rays: Integrator::color_at for arbitrary rays).
+struct OneRay {
+  d3 o, d;
+  bool pending;
+  d3 color;
+  __device__ __forceinline__ bool next(d3& oo, d3& dd) {
+    if (!pending) return false;
+    pending = false;
+    oo = o;
+    dd = d;
+    return true;
+  }
+  __device__ __forceinline__ void add(d3 c) { color = c; }
+};
+
+template <bool STATS, class Rays>
+__device__ __forceinline__ void run_machine(const DevScene& s, const DevOptions& opt, Rays& rays, bool lane_has_work, uint2* lds,
+                                            Counters& cnt) {
+  Frame frames[RT_FRAMES];
+  Trav T;
+  T.cur = RT_FREF_NONE;
+  T.sp = 0;
+  T.mode = M_CLOSEST;
+  T.limit = 0.;
+  int depth = 0;
+  bool finished = !lane_has_work;
+  if (!finished) {
+    d3 o, d;
+    if (rays.next(o, d)) {
+      if (STATS) cnt.rays_primary++;
+      trav_start(T, o, d, M_CLOSEST, INFINITY);
+      frames[0].pc = PC_AFTER_CLOSEST;
+    } else {
+      finished = true;
+    }
+  }
+  while (__builtin_amdgcn_ballot_w64(!finished) != 0ull) {
+    trav_run<STATS>(s, T, lds, cnt);
+    if (finished) continue;
+    // ---- the lane's traversal is complete: advance its state machine to the next ray ----
+    uint32_t pc = frames[depth].pc;
+    d3 ret = mk3(0., 0., 0.);        // colour returned by a finished frame
+    d3 refracted = mk3(0., 0., 0.);
+    double ht = 0., hu = 0., hv = 0., n1 = 1., n2 = 1.;
+    uint32_t hprim = RT_NONE;
+    do {
+      Frame& F = frames[depth];
+      if (pc == PC_AFTER_CLOSEST) {
+        if (T.p == RT_NONE) {  // miss: black (integrator.rs:62-65)
+          ret = mk3(0., 0., 0.);
+          pc = PC_RETURN;
+        } else {
+          hprim = T.p;
+          ht = T.limit;
+          hu = T.a;
+          hv = T.b;
+          n1 = 1.0;  // AIR_REFRACTIVE_INDEX (material.rs:7)
+          n2 = 1.0;
+          uint32_t m = s.prim_info[hprim].y;
+          if (!approx_eq(s.material[(size_t)m * RT_MAT_STRIDE + RT_MAT_TRANSPARENCY], 0.)) {
+            // Intersection::compute_refractive (intersection.rs:184-190) needs the negative-t intersections of this ray
+            F.t = ht;
+            F.u = hu;
+            F.v = hv;
+            F.prim = hprim;
+            F.pc = PC_AFTER_CONTAINERS;
+            d3 o = T.o, d = T.d;
+            trav_start(T, o, d, M_CONTAINERS, 0.);
+            T.h = hprim;
+            pc = PC_TRACE;
+          } else {
+            pc = PC_HIT_READY;
+          }
+        }
+      }
+      if (pc == PC_AFTER_CONTAINERS) {  // get_refractive (intersection.rs:258-302)
+        hprim = F.prim;
+        ht = F.t;
+        hu = F.u;
+        hv = F.v;
+        n1 = 1.0;
+        n2 = 1.0;
+        if (T.p != RT_NONE) n1 = s.material[(size_t)s.prim_info[T.p].y * RT_MAT_STRIDE + RT_MAT_REFRACTIVE_INDEX];
+        if (T.flag) {  // the hit object leaves the container list
+          uint32_t last = (T.p == hprim) ? T.q : T.p;
+          if (last != RT_NONE) n2 = s.material[(size_t)s.prim_info[last].y * RT_MAT_STRIDE + RT_MAT_REFRACTIVE_INDEX];
+        } else {  // the hit object becomes the innermost container
+          n2 = s.material[(size_t)s.prim_info[hprim].y * RT_MAT_STRIDE + RT_MAT_REFRACTIVE_INDEX];
+        }
+        pc = PC_HIT_READY;
+      }
+      if (pc == PC_HIT_READY) {  // IntersecComputations::new (intersection.rs:217-256)
+        uint4 info = s.prim_info[hprim];
+        const double* mat = s.material + (size_t)info.y * RT_MAT_STRIDE;
+        HitGeom g = hit_geom(s, info, T.o, T.d, ht, hu, hv);
+        F.prim = hprim;
+        F.n1 = n1;
+        F.n2 = n2;
+        st3(F.over, g.over);
+        st3(F.under, g.under);
+        st3(F.eye, g.eye);
+        st3(F.normal, g.normal);
+        st3(F.refl, mk3(0., 0., 0.));
+        if (STATS) {  // algorithmic bytes of shading this hit
+          cnt.hits++;
+          uint32_t b = 64u + 48u * s.n_lights;
+          b += info.x == RT_SHAPE_SMOOTH_TRIANGLE ? 72u : (info.x == RT_SHAPE_TRIANGLE ? 24u : (info.z != RT_NONE ? 96u : 0u));
+          if (s.pattern_kind[info.y] != RT_PATTERN_CONST) b += 144u;
+          cnt.hit_bytes += b;
+        }
+        // reflected_color_at_depth (integrator.rs:154-168)
+        if ((uint32_t)depth < opt.max_depth && !approx_eq(mat[RT_MAT_REFLECTIVITY], 0.)) {
+          F.pc = PC_AFTER_REFLECT;
+          depth++;
+          frames[depth].pc = PC_AFTER_CLOSEST;
+          if (STATS) cnt.rays_reflect++;
+          trav_start(T, g.over, g.reflect_v, M_CLOSEST, INFINITY);
+          pc = PC_TRACE;
+        } else {
+          pc = PC_REFRACT;
+        }
+      }
+      if (pc == PC_AFTER_REFLECT) {  // color * reflectivity (integrator.rs:167)
+        double kr = s.material[(size_t)s.prim_info[F.prim].y * RT_MAT_STRIDE + RT_MAT_REFLECTIVITY];
+        st3(F.refl, mk3(ret.x * kr, ret.y * kr, ret.z * kr));
+        pc = PC_REFRACT;
+      }
+      if (pc == PC_REFRACT) {  // refracted_color_at_depth (integrator.rs:170-197)
+        const double* mat = s.material + (size_t)s.prim_info[F.prim].y * RT_MAT_STRIDE;
+        refracted = mk3(0., 0., 0.);
+        pc = PC_LIGHTS;
+        if ((uint32_t)depth < opt.max_depth && !approx_eq(mat[RT_MAT_TRANSPARENCY], 0.)) {
+          d3 eye = ld3(F.eye), normal = ld3(F.normal);
+          double ratio = F.n1 / F.n2;
+          double cos_i = dot3(eye, normal);
+          double sin2_t = (ratio * ratio) * (1. - cos_i * cos_i);
+          if (!(sin2_t > 1.)) {
+            double cos_t = sqrt(1. - sin2_t);
+            d3 dir = sub3(scale3(normal, ratio * cos_i - cos_t), scale3(eye, ratio));
+            F.pc = PC_AFTER_REFRACT;
+            d3 under = ld3(F.under);
+            depth++;
+            frames[depth].pc = PC_AFTER_CLOSEST;
+            if (STATS) cnt.rays_refract++;
+            trav_start(T, under, dir, M_CLOSEST, INFINITY);
+            pc = PC_TRACE;
+          }
+        }
+      }
+      if (pc == PC_AFTER_REFRACT) {  // color * transparency (integrator.rs:196)
+        double kt = s.material[(size_t)s.prim_info[F.prim].y * RT_MAT_STRIDE + RT_MAT_TRANSPARENCY];
+        refracted = mk3(ret.x * kt, ret.y * kt, ret.z * kt);
+        pc = PC_LIGHTS;
+      }
+      if (pc == PC_LIGHTS) {  // shade_hit_at_depth (integrator.rs:199-228): the terms that do not depend on the light
+        const double* mat = s.material + (size_t)s.prim_info[F.prim].y * RT_MAT_STRIDE;
+        d3 reflected = ld3(F.refl);
+        double kr = mat[RT_MAT_REFLECTIVITY], kt = mat[RT_MAT_TRANSPARENCY];
+        bool use_schlick = kr > 0. && kt > 0. && !approx_eq(kr, 0.) && !approx_eq(kt, 0.);
+        d3 rr;
+        if (use_schlick) {
+          double reflectance = schlick(ld3(F.eye), ld3(F.normal), F.n1, F.n2);
+          double k2 = 1. - reflectance;
+          rr = mk3(reflected.x * reflectance + refracted.x * k2, reflected.y * reflectance + refracted.y * k2,
+                   reflected.z * reflectance + refracted.z * k2);
+        } else {
+          rr = add3(reflected, refracted);
+        }
+        st3(F.rr, rr);
+        st3(F.acc, mk3(0., 0., 0.));
+        if (s.n_lights == 0) {
+          ret = mk3(0., 0., 0.);
+          pc = PC_RETURN;
+        } else {
+          pc = PC_AFTER_SHADOW;  // falls into the shadow-ray set-up below with light 0
+          F.light = RT_NONE;
+        }
+      }
+      if (pc == PC_AFTER_SHADOW) {
+        uint32_t l = F.light;
+        d3 over = ld3(F.over);
+        if (l != RT_NONE) {  // a shadow traversal for light l has just finished
+          uint4 info = s.prim_info[F.prim];
+          const double* mat = s.material + (size_t)info.y * RT_MAT_STRIDE;
+          double shadow = fmin(T.a, 1.);  // IntersectionCollector::shadow_intensity (intersection.rs:124-126)
+          if (!opt.shadow_intensity) shadow = approx_eq(shadow, 0.) ? 0. : 1.;
+          d3 surface = lighting(s, l, info, mat, over, ld3(F.eye), ld3(F.normal), shadow);
+          d3 acc = add3(add3(ld3(F.acc), surface), ld3(F.rr));  // acc + surface + reflected_refracted
+          st3(F.acc, acc);
+          l++;
+        } else {
+          l = 0;
+        }
+        if (l < s.n_lights) {  // point_shadow_intensity_comps (integrator.rs:136-152) from over_point
+          const double* lp = s.light_pos + (size_t)l * 3;
+          d3 vv = sub3(mk3(lp[0], lp[1], lp[2]), over);
+          double dist = mag3(vv);
+          d3 sdir = normalize3(vv);
+          F.light = l;
+          F.pc = PC_AFTER_SHADOW;
+          if (STATS) cnt.rays_shadow++;
+          trav_start(T, over, sdir, M_SHADOW, dist);
+          pc = PC_TRACE;
+        } else {
+          ret = ld3(F.acc);
+          pc = PC_RETURN;
+        }
+      }
+      if (pc == PC_RETURN) {
+        if (depth == 0) {  // Renderer::color_at_pixel: next sample (renderer.rs:57-64)
+          rays.add(ret);
+          d3 o, d;
+          if (rays.next(o, d)) {
+            if (STATS) cnt.rays_primary++;
+            trav_start(T, o, d, M_CLOSEST, INFINITY);
+            frames[0].pc = PC_AFTER_CLOSEST;
+            pc = PC_TRACE;
+          } else {
+            finished = true;
+            T.cur = RT_FREF_NONE;
+            pc = PC_DONE;
+          }
+        } else {
+          depth--;
+          pc = frames[depth].pc;  // PC_AFTER_REFLECT or PC_AFTER_REFRACT of the parent
+        }
+      }
+    } while (pc != PC_TRACE && pc != PC_DONE);
+  }
+}
+
+}  // namespace fast

@@ -1,0 +1,272 @@
+// rt_shapes.h — ray/shape intersection in object space and the AABB slab test, f64, reference operation order.
+// Shared by the fast traversal (rt_fast.h) and the reference-order traversal (rt_reforder.h).
+#pragma once
+#include "rt_device.h"
+
+struct Counters {
+  uint32_t rays_primary, rays_shadow, rays_reflect, rays_refract, node_visits, tri_tests, prim_tests, hits, hit_bytes, overflow;
+  uint32_t wave_steps, lane_steps;  // fast path: traversal steps of the wavefront / lanes active in them
+};
+
+// ---------------------------------------------------------------------------------------------
+// Shapes: local intersect in object space.  Each returns the number of roots written to ts[0..4).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ int sphere_roots(d3 o, d3 d, double* ts) {  // sphere.rs:20-35
+  d3 sr = sub3(o, mk3(0., 0., 0.));
+  double a = dot3(d, d);
+  double b = 2. * dot3(d, sr);
+  double c = dot3(sr, sr) - 1.;
+  double disc = b * b - 4. * a * c;
+  if (disc < 0. || a == 0.) return 0;
+  double ds = sqrt(disc);
+  ts[0] = (-b - ds) / (2. * a);
+  ts[1] = (-b + ds) / (2. * a);
+  return 2;
+}
+
+__device__ __forceinline__ int plane_roots(d3 o, d3 d, double* ts) {  // plane.rs:13-19
+  if (approx_eq(d.y, 0.)) return 0;
+  ts[0] = -o.y / d.y;
+  return 1;
+}
+
+__device__ __forceinline__ void cube_axis(double origin, double dir_inv, double& tmin, double& tmax) {  // cube.rs:51-63
+  double a = (-1. - origin) * dir_inv;
+  double b = (1. - origin) * dir_inv;
+  if (a < b) { tmin = a; tmax = b; } else { tmin = b; tmax = a; }
+}
+__device__ __forceinline__ int cube_roots(d3 o, d3 dinv, double* ts) {  // cube.rs:25-42
+  double xmin, xmax, ymin, ymax, zmin, zmax;
+  cube_axis(o.x, dinv.x, xmin, xmax);
+  cube_axis(o.y, dinv.y, ymin, ymax);
+  cube_axis(o.z, dinv.z, zmin, zmax);
+  double tmin = fmax(fmax(xmin, ymin), zmin);
+  double tmax = fmin(fmin(xmax, ymax), zmax);
+  if (tmin > tmax) return 0;
+  ts[0] = tmin;
+  ts[1] = tmax;
+  return 2;
+}
+
+__device__ __forceinline__ int cylinder_roots(d3 o, d3 d, double y_min, double y_max, bool closed, double* ts) {  // cylinder.rs:54-120
+  if (approx_eq(y_min, y_max)) return 0;
+  int n = 0;
+  if (closed && !approx_eq(d.y, 0.)) {  // caps first (:107-120), radius test x^2+z^2 <= 1 (:101-106)
+    double tmin = (y_min - o.y) / d.y;
+    double tmax = (y_max - o.y) / d.y;
+    double x = o.x + tmin * d.x, z = o.z + tmin * d.z;
+    if (x * x + z * z <= 1.) ts[n++] = tmin;
+    x = o.x + tmax * d.x;
+    z = o.z + tmax * d.z;
+    if (x * x + z * z <= 1.) ts[n++] = tmax;
+  }
+  double a = d.x * d.x + d.z * d.z;
+  if (approx_eq(a, 0.)) return n;
+  double b = 2. * o.x * d.x + 2. * o.z * d.z;
+  double c = o.x * o.x + o.z * o.z - 1.;
+  double disc = b * b - 4. * a * c;
+  if (disc < 0.) return n;
+  double ds = sqrt(disc);
+  double t0 = (-b - ds) / (2. * a);
+  double t1 = (-b + ds) / (2. * a);
+  double y0 = o.y + t0 * d.y;
+  if (y_min < y0 && y0 < y_max) ts[n++] = t0;
+  double y1 = o.y + t1 * d.y;
+  if (y_min < y1 && y1 < y_max) ts[n++] = t1;
+  return n;
+}
+
+__device__ __forceinline__ int cone_roots(d3 o, d3 d, double y_min, double y_max, bool closed, double* ts) {  // cone.rs:56-127
+  if (approx_eq(y_min, y_max)) return 0;
+  int n = 0;
+  if (closed && !approx_eq(d.y, 0.)) {  // caps: squared distance against |y| (sic, :106-112,121,124)
+    double tmin = (y_min - o.y) / d.y;
+    double tmax = (y_max - o.y) / d.y;
+    double x = o.x + tmin * d.x, z = o.z + tmin * d.z;
+    if (x * x + z * z <= fabs(y_min)) ts[n++] = tmin;
+    x = o.x + tmax * d.x;
+    z = o.z + tmax * d.z;
+    if (x * x + z * z <= fabs(y_max)) ts[n++] = tmax;
+  }
+  double a = d.x * d.x - d.y * d.y + d.z * d.z;
+  double b = 2. * (o.x * d.x - o.y * d.y + o.z * d.z);
+  double c = o.x * o.x - o.y * o.y + o.z * o.z;
+  if (approx_eq(a, 0.)) {
+    if (approx_eq(b, 0.)) return n;
+    ts[n++] = -c / (2. * b);  // no y-range check (:71-76)
+    return n;
+  }
+  double disc = b * b - 4. * a * c;
+  if (disc < 0.) return n;
+  double ds = sqrt(disc);
+  double t0 = (-b - ds) / (2. * a);
+  double t1 = (-b + ds) / (2. * a);
+  double y0 = o.y + t0 * d.y;
+  if (y_min < y0 && y0 < y_max) ts[n++] = t0;
+  double y1 = o.y + t1 * d.y;
+  if (y_min < y1 && y1 < y_max) ts[n++] = t1;
+  return n;
+}
+
+// Moeller-Trumbore exactly as triangle.rs:48-71 / smooth_triangle.rs:60-83
+__device__ __forceinline__ int triangle_roots(const double* __restrict__ tri, d3 o, d3 d, double* ts, double& u, double& v) {
+  d3 p1 = mk3(tri[0], tri[1], tri[2]);
+  d3 e1 = mk3(tri[3], tri[4], tri[5]);
+  d3 e2 = mk3(tri[6], tri[7], tri[8]);
+  d3 dir_cross_e2 = cross3(d, e2);
+  double det = dot3(e1, dir_cross_e2);
+  if (approx_eq(det, 0.)) return 0;
+  double f = 1. / det;
+  d3 p1_to_origin = sub3(o, p1);
+  u = f * dot3(p1_to_origin, dir_cross_e2);
+  if (!(u >= 0. && u <= 1.)) return 0;
+  d3 origin_cross_e1 = cross3(p1_to_origin, e1);
+  v = f * dot3(d, origin_cross_e1);
+  if (v < 0. || u + v > 1.) return 0;
+  ts[0] = f * dot3(e2, origin_cross_e1);
+  return 1;
+}
+
+// BoundingBox::intersection_time (bounding_box.rs:192-225); no tmax < 0 rejection, NaN dropped by fmax/fmin
+__device__ __forceinline__ void axis_times(double origin, double dir_inv, double mn, double mx, double& tmin, double& tmax) {
+  double a = (mn - origin) * dir_inv;
+  double b = (mx - origin) * dir_inv;
+  if (a < b) { tmin = a; tmax = b; } else { tmin = b; tmax = a; }
+}
+__device__ __forceinline__ bool bbox_time(const double* bb, d3 o, d3 dinv, double& out) {
+  double xmin, xmax, ymin, ymax, zmin, zmax;
+  axis_times(o.x, dinv.x, bb[0], bb[3], xmin, xmax);
+  axis_times(o.y, dinv.y, bb[1], bb[4], ymin, ymax);
+  double tmin = fmax(xmin, ymin);
+  double tmax = fmin(xmax, ymax);
+  if (tmin > tmax) return false;
+  axis_times(o.z, dinv.z, bb[2], bb[5], zmin, zmax);
+  tmin = fmax(tmin, zmin);
+  tmax = fmin(tmax, zmax);
+  if (tmin > tmax) return false;
+  out = tmin;
+  return true;
+}
+
+// PrimitiveObject::intersect (object.rs:432-439) + Shape::local_intersect (shape.rs:51-62)
+template <bool STATS>
+__device__ __forceinline__ int prim_roots(const DevScene& s, uint4 info, d3 o, d3 d, d3 dinv, double* ts, double& u, double& v,
+                                          Counters& cnt) {
+  uint32_t shape = info.x;
+  u = -INFINITY;
+  v = -INFINITY;
+  if (shape >= RT_SHAPE_TRIANGLE && shape != RT_SHAPE_BBOX) {
+    if (STATS) cnt.tri_tests++;
+    double uu, vv;
+    int n = triangle_roots(s.tri_isect + (size_t)info.w * RT_TRI_STRIDE, o, d, ts, uu, vv);
+    if (n && shape == RT_SHAPE_SMOOTH_TRIANGLE) {  // add_uv (intersection.rs:104-109); flat: u = v = -inf (:156-163)
+      u = uu;
+      v = vv;
+    }
+    return n;
+  }
+  if (STATS) cnt.prim_tests++;
+  if (info.z != RT_NONE) {  // Ray::transform_new (ray.rs:21-23) -> Ray::new recomputes dir_inv (ray.rs:27-34)
+    const double* m = s.xform_inv + (size_t)info.z * 16;
+    o = mat_point(m, o);
+    d = mat_vector(m, d);
+    dinv = mk3(1. / d.x, 1. / d.y, 1. / d.z);
+  }
+  switch (shape) {
+    case RT_SHAPE_SPHERE: return sphere_roots(o, d, ts);
+    case RT_SHAPE_PLANE: return plane_roots(o, d, ts);
+    case RT_SHAPE_CUBE:
+    case RT_SHAPE_BBOX: return cube_roots(o, dinv, ts);
+    case RT_SHAPE_CYLINDER: {
+      const double* q = s.quadric + (size_t)info.w * 2;
+      return cylinder_roots(o, d, q[0], q[1], s.quadric_closed[info.w] != 0, ts);
+    }
+    default: {
+      const double* q = s.quadric + (size_t)info.w * 2;
+      return cone_roots(o, d, q[0], q[1], s.quadric_closed[info.w] != 0, ts);
+    }
+  }
+}
+
+#define RT_CSG_LIST_MAX 16   // hits kept per outermost CSG evaluation
+#define RT_CSG_NEST_MAX 4    // nested CSG objects
+
+// ---------------------------------------------------------------------------------------------
+// CSG: CsgObject::intersect (csg.rs:112-122).  Children are primitives or nested CSG objects
+// (groups inside CSG are rejected at scene creation).  Iterative over an explicit frame stack; the
+// hit list doubles as the nested collectors: a child CSG's survivors stay in place for its parent.
+// ---------------------------------------------------------------------------------------------
+struct CsgHit {
+  double t, u, v;
+  uint32_t prim;
+};
+
+// Fills list[0..n) with the surviving intersections of the outermost CSG object `csg_root`, ascending t.
+template <bool STATS>
+__device__ __forceinline__ int csg_survivors(const DevScene& s, uint32_t csg_root, d3 o, d3 d, d3 dinv, CsgHit* list, Counters& cnt) {
+  uint32_t f_csg[RT_CSG_NEST_MAX];
+  uint8_t f_stage[RT_CSG_NEST_MAX];
+  uint8_t f_start[RT_CSG_NEST_MAX];
+  int n = 0, fp = 0;
+  f_csg[0] = csg_root;
+  f_stage[0] = 0;
+  f_start[0] = 0;
+  while (fp >= 0) {
+    uint32_t csg = f_csg[fp];
+    if (f_stage[fp] < 2) {
+      uint32_t ref = f_stage[fp] == 0 ? s.csg_left[csg] : s.csg_right[csg];
+      f_stage[fp]++;
+      uint32_t kind = ref >> RT_REF_KIND_SHIFT, idx = ref & RT_REF_INDEX_MASK;
+      if (kind == RT_REF_PRIM) {
+        double ts[4], u, v;
+        int k = prim_roots<STATS>(s, s.prim_info[idx], o, d, dinv, ts, u, v, cnt);
+        for (int i = 0; i < k; i++) {
+          if (n < RT_CSG_LIST_MAX) {
+            list[n].t = ts[i];
+            list[n].u = u;
+            list[n].v = v;
+            list[n].prim = idx;
+            n++;
+          } else {
+            cnt.overflow = 1;
+          }
+        }
+      } else if (kind == RT_REF_CSG && fp + 1 < RT_CSG_NEST_MAX) {
+        fp++;
+        f_csg[fp] = idx;
+        f_stage[fp] = 0;
+        f_start[fp] = (uint8_t)n;
+      }
+      continue;
+    }
+    // both children collected: sort (collect_sorted, intersection.rs:110-114; stable insertion sort == the
+    // reference's sort for short slices) and filter (csg.rs:87-111)
+    int start = f_start[fp];
+    for (int i = start + 1; i < n; i++) {
+      CsgHit h = list[i];
+      int j = i - 1;
+      while (j >= start && list[j].t > h.t) {
+        list[j + 1] = list[j];
+        j--;
+      }
+      list[j + 1] = h;
+    }
+    bool inside_left = false, inside_right = false;
+    uint32_t op = s.csg_op[csg];
+    uint32_t depth = s.csg_depth[csg];
+    int w = start;
+    for (int i = start; i < n; i++) {
+      bool hit_left = (s.prim_csg_left[list[i].prim] >> depth) & 1u;  // self.left.includes(i.object())
+      if (hit_left) inside_left = !inside_left;
+      else inside_right = !inside_right;
+      bool allowed;
+      if (op == RT_CSG_UNION) allowed = hit_left ? !inside_right : !inside_left;
+      else if (op == RT_CSG_INTERSECTION) allowed = hit_left ? inside_right : inside_left;
+      else allowed = hit_left ? !inside_right : inside_left;
+      if (allowed) list[w++] = list[i];
+    }
+    n = w;
+    fp--;
+  }
+  return n;
+}

@@ -7,26 +7,28 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <algorithm>
 #include <string>
+#include <utility>
 #include <vector>
 
-#include "rt_kernels.h"
+#include "rt_fast.h"
+#include "rt_reforder.h"
 
 // ---------------------------------------------------------------------------------------------
 // kernels
 // ---------------------------------------------------------------------------------------------
-#define RT_N_COUNTERS 10
+#define RT_N_COUNTERS 12
 #ifndef RT_WAVES_PER_EU
-#define RT_WAVES_PER_EU 1  // minimum waves per SIMD the register allocator must leave room for
+#define RT_WAVES_PER_EU 4  // waves per SIMD the register allocator must leave room for (128 VGPRs)
 #endif
 
 template <bool STATS>
 __device__ __forceinline__ void flush_counters(const Counters& c, unsigned long long* stats, uint32_t* overflow_flag) {
   if (c.overflow) atomicOr(overflow_flag, 1u);
   if (!STATS) return;
-  uint32_t v[RT_N_COUNTERS] = {c.rays_primary, c.rays_shadow, c.rays_reflect, c.rays_refract,
-                               c.node_visits,  c.tri_tests,   c.prim_tests,   c.hits,
-                               c.hit_bytes,    c.overflow};
+  uint32_t v[RT_N_COUNTERS] = {c.rays_primary, c.rays_shadow, c.rays_reflect, c.rays_refract, c.node_visits, c.tri_tests,
+                               c.prim_tests,   c.hits,        c.hit_bytes,    c.overflow,     c.wave_steps,  c.lane_steps};
   for (int k = 0; k < RT_N_COUNTERS; k++) {
     unsigned long long x = v[k];
     for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
@@ -44,31 +46,46 @@ __device__ __forceinline__ uint32_t xcd_remap(uint32_t bid, uint32_t n) {
 }
 
 // Renderer::color_at_pixel (renderer.rs:50-66) for one 8x8 tile per wavefront.
-template <bool STATS>
-__global__ __launch_bounds__(64, RT_WAVES_PER_EU) void render_tiles_kernel(DevScene s, rt_camera cam, DevOptions opt, uint32_t part,
-                                                          uint32_t n_parts, uint32_t tiles_x, uint32_t n_owned, int packed,
-                                                          double* __restrict__ out, unsigned long long* stats,
-                                                          uint32_t* overflow_flag) {
+// REFORDER = false: the production core (rt_fast.h).  REFORDER = true: reference visiting order (rt_reforder.h).
+template <bool STATS, bool REFORDER>
+__global__ __launch_bounds__(64, REFORDER ? 2 : RT_WAVES_PER_EU) void render_tiles_kernel(DevScene s, rt_camera cam, DevOptions opt, uint32_t part,
+                                                                            uint32_t n_parts, uint32_t tiles_x, uint32_t n_owned,
+                                                                            int packed, double* __restrict__ out,
+                                                                            unsigned long long* stats, uint32_t* overflow_flag) {
+  __shared__ uint2 lds_stack[RT_LDS_STACK * 64];
   uint32_t k = xcd_remap(blockIdx.x, n_owned);
   uint32_t tile = k * n_parts + part;
   uint32_t lane = threadIdx.x;
   uint32_t px = (tile % tiles_x) * RT_TILE_DIM + (lane & 7u);
   uint32_t py = (tile / tiles_x) * RT_TILE_DIM + (lane >> 3);
-  Counters cnt = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  Counters cnt = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   bool inside = px < cam.width && py < cam.height;
   d3 color = mk3(0., 0., 0.);
-  if (inside) {
-    double x = (double)px, y = (double)py;
-    for (uint32_t i = 0; i < opt.n_offsets; i++)
-      for (uint32_t j = 0; j < opt.n_offsets; j++) {  // dx outer, dy inner (renderer.rs:57-64)
-        d3 o, d;
-        camera_ray(cam, x + opt.offsets[i], y + opt.offsets[j], o, d);
-        if (STATS) cnt.rays_primary++;
-        color = add3(color, trace<STATS>(s, opt, o, d, cnt));
-      }
-    double nn = (double)(opt.n_offsets * opt.n_offsets);
-    color = mk3(color.x / nn, color.y / nn, color.z / nn);
+  if (REFORDER) {
+    if (inside) {
+      double x = (double)px, y = (double)py;
+      for (uint32_t i = 0; i < opt.n_offsets; i++)
+        for (uint32_t j = 0; j < opt.n_offsets; j++) {  // dx outer, dy inner (renderer.rs:57-64)
+          d3 o, d;
+          camera_ray(cam, x + opt.offsets[i], y + opt.offsets[j], o, d);
+          if (STATS) cnt.rays_primary++;
+          color = add3(color, reforder::trace<STATS>(s, opt, o, d, cnt));
+        }
+    }
+  } else {
+    fast::PixelRays rays;
+    rays.cam = &cam;
+    rays.opt = &opt;
+    rays.x = (double)px;
+    rays.y = (double)py;
+    rays.k = 0;
+    rays.n = opt.n_offsets * opt.n_offsets;
+    rays.color = mk3(0., 0., 0.);
+    fast::run_machine<STATS>(s, opt, rays, inside, lds_stack + lane, cnt);
+    color = rays.color;
   }
+  double nn = (double)(opt.n_offsets * opt.n_offsets);
+  color = mk3(color.x / nn, color.y / nn, color.z / nn);  // renderer.rs:65
   if (packed) {
     double* dst = out + ((size_t)k * 64 + lane) * 3;
     dst[0] = color.x;
@@ -119,15 +136,32 @@ __global__ __launch_bounds__(256) void quantize_kernel(const double* __restrict_
 }
 
 // Integrator::color_at for arbitrary rays (one lane per ray)
-__global__ __launch_bounds__(64, RT_WAVES_PER_EU) void trace_rays_kernel(DevScene s, DevOptions opt, uint32_t n, const double* __restrict__ origin,
-                                                        const double* __restrict__ dir, double* __restrict__ out,
-                                                        uint32_t* overflow_flag) {
+template <bool REFORDER>
+__global__ __launch_bounds__(64, REFORDER ? 2 : RT_WAVES_PER_EU) void trace_rays_kernel(DevScene s, DevOptions opt, uint32_t n,
+                                                                          const double* __restrict__ origin,
+                                                                          const double* __restrict__ dir, double* __restrict__ out,
+                                                                          uint32_t* overflow_flag) {
+  __shared__ uint2 lds_stack[RT_LDS_STACK * 64];
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  Counters cnt = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-  if (i < n) {
-    d3 o = mk3(origin[3 * i], origin[3 * i + 1], origin[3 * i + 2]);
-    d3 d = mk3(dir[3 * i], dir[3 * i + 1], dir[3 * i + 2]);
-    d3 c = trace<false>(s, opt, o, d, cnt);
+  Counters cnt = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  bool valid = i < n;
+  d3 o = mk3(0., 0., 0.), d = mk3(0., 0., 1.), c = mk3(0., 0., 0.);
+  if (valid) {
+    o = mk3(origin[3 * i], origin[3 * i + 1], origin[3 * i + 2]);
+    d = mk3(dir[3 * i], dir[3 * i + 1], dir[3 * i + 2]);
+  }
+  if (REFORDER) {
+    if (valid) c = reforder::trace<false>(s, opt, o, d, cnt);
+  } else {
+    fast::OneRay rays;
+    rays.o = o;
+    rays.d = d;
+    rays.pending = true;
+    rays.color = mk3(0., 0., 0.);
+    fast::run_machine<false>(s, opt, rays, valid, lds_stack + threadIdx.x, cnt);
+    c = rays.color;
+  }
+  if (valid) {
     out[3 * i] = c.x;
     out[3 * i + 1] = c.y;
     out[3 * i + 2] = c.z;
@@ -213,6 +247,165 @@ uint32_t stack_need(const rt_scene_desc* d, uint32_t node, std::vector<int64_t>&
   }
   memo[node] = need;
   return need;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Device layout of the fast path (rt_device.h): binary 128-B nodes, leaf runs, visit ranks.
+// ---------------------------------------------------------------------------------------------
+struct FastLayout {
+  std::vector<DevNode> nodes;
+  std::vector<uint32_t> leaf_ref;
+  std::vector<uint32_t> prim_rank;
+  std::vector<uint32_t> prim_tri;  // triangle primitives: slot in the device triangle tables (leaf order), else RT_NONE
+  uint32_t n_dev_tris = 0;
+  uint32_t depth = 0;
+  std::string error;
+};
+
+struct FastItem {  // how a parent refers to one child: reference + the box tested before entering it
+  uint32_t ref;
+  double bb[6];
+};
+
+bool is_triangle_prim(const rt_scene_desc* d, uint32_t prim) {
+  uint8_t sh = d->prim_shape[prim];
+  return (sh == RT_SHAPE_TRIANGLE || sh == RT_SHAPE_SMOOTH_TRIANGLE) && d->prim_xform[prim] == RT_NONE;
+}
+
+// Visit order of ObjectGroup::intersect_iter (group.rs:171-201): a popped group handles its children in reverse,
+// primitives and CSG objects at once, sub-groups pushed (so they pop in forward order).  Every leaf primitive of a
+// CSG object shares the CSG's rank (its survivors reach the collector in one push sequence, csg.rs:119-121).
+void assign_ranks(const rt_scene_desc* d, std::vector<uint32_t>& rank) {
+  rank.assign(d->n_prims, 0xFFFFFFFFu);
+  uint32_t next = 0;
+  std::vector<uint32_t> stack{0};
+  std::vector<uint32_t> csg_stack;
+  while (!stack.empty()) {
+    uint32_t g = stack.back();
+    stack.pop_back();
+    uint32_t b = d->node_child_begin[g], e = d->node_child_begin[g + 1];
+    for (uint32_t i = e; i-- > b;) {
+      uint32_t ref = d->child_ref[i], kind = ref >> RT_REF_KIND_SHIFT, idx = ref & RT_REF_INDEX_MASK;
+      if (kind == RT_REF_NODE) {
+        stack.push_back(idx);
+      } else if (kind == RT_REF_PRIM) {
+        rank[idx] = next++;
+      } else {
+        uint32_t r = next++;
+        csg_stack.assign(1, idx);
+        while (!csg_stack.empty()) {
+          uint32_t c = csg_stack.back();
+          csg_stack.pop_back();
+          for (uint32_t cr : {d->csg_left[c], d->csg_right[c]}) {
+            uint32_t ck = cr >> RT_REF_KIND_SHIFT, ci = cr & RT_REF_INDEX_MASK;
+            if (ck == RT_REF_PRIM) rank[ci] = r;
+            else if (ck == RT_REF_CSG) csg_stack.push_back(ci);
+          }
+        }
+      }
+    }
+  }
+}
+
+// Emits the reference(s) for a run of direct primitive/CSG children of one group, tested behind `bb` (the group's box).
+// More than RT_FREF_LEAF_MAX of them become several leaves.
+void make_leaves(const rt_scene_desc* d, FastLayout& L, const std::vector<uint32_t>& refs, const double* bb, std::vector<FastItem>& out) {
+  bool all_tris = !refs.empty();
+  for (uint32_t r : refs)
+    if ((r >> RT_REF_KIND_SHIFT) != RT_REF_PRIM || !is_triangle_prim(d, r & RT_REF_INDEX_MASK) || L.prim_tri[r & RT_REF_INDEX_MASK] != RT_NONE)
+      all_tris = false;
+  for (size_t at = 0; at < refs.size(); at += RT_FREF_LEAF_MAX) {
+    uint32_t n = (uint32_t)std::min<size_t>(RT_FREF_LEAF_MAX, refs.size() - at);
+    FastItem it;
+    std::memcpy(it.bb, bb, sizeof(it.bb));
+    if (all_tris) {
+      it.ref = RT_MAKE_FREF(RT_FREF_TRIS, n, L.n_dev_tris);
+      for (uint32_t k = 0; k < n; k++) L.prim_tri[refs[at + k] & RT_REF_INDEX_MASK] = L.n_dev_tris++;
+    } else {
+      it.ref = RT_MAKE_FREF(RT_FREF_PRIMS, n, (uint32_t)L.leaf_ref.size());
+      for (uint32_t k = 0; k < n; k++) L.leaf_ref.push_back(refs[at + k]);
+    }
+    out.push_back(it);
+  }
+}
+
+// Folds items into binary nodes; returns the reference to the (sub)tree holding all of them.  Synthetic inner
+// references are tested behind `bb` again (a box the ray is already known to hit).
+uint32_t fold_items(FastLayout& L, const std::vector<FastItem>& items, size_t from, const double* bb) {
+  uint32_t id = (uint32_t)L.nodes.size();
+  L.nodes.emplace_back();
+  std::memset(&L.nodes[id], 0, sizeof(DevNode));
+  DevNode n;
+  std::memset(&n, 0, sizeof(n));
+  std::memcpy(n.bb[0], items[from].bb, sizeof(n.bb[0]));
+  n.ref[0] = items[from].ref;
+  size_t left = items.size() - from;
+  if (left == 1) {
+    n.ref[1] = RT_FREF_NONE;
+  } else if (left == 2) {
+    std::memcpy(n.bb[1], items[from + 1].bb, sizeof(n.bb[1]));
+    n.ref[1] = items[from + 1].ref;
+  } else {
+    std::memcpy(n.bb[1], bb, sizeof(n.bb[1]));
+    n.ref[1] = fold_items(L, items, from + 1, bb);
+  }
+  L.nodes[id] = n;
+  return RT_MAKE_FREF(RT_FREF_INNER, 0, id);
+}
+
+// How the parent of group `g` refers to it (the box is g's own, tested by the parent).
+uint32_t build_group(const rt_scene_desc* d, FastLayout& L, uint32_t g, uint32_t depth) {
+  if (depth > L.depth) L.depth = depth;
+  if (depth > 4096) {
+    L.error = "group nesting deeper than 4096";
+    return RT_FREF_NONE;
+  }
+  const double* bb = d->node_bbox + (size_t)g * 6;
+  uint32_t b = d->node_child_begin[g], e = d->node_child_begin[g + 1];
+  std::vector<uint32_t> direct, groups;
+  for (uint32_t i = b; i < e; i++) {
+    uint32_t ref = d->child_ref[i];
+    if ((ref >> RT_REF_KIND_SHIFT) == RT_REF_NODE) groups.push_back(ref & RT_REF_INDEX_MASK);
+    else direct.push_back(ref);
+  }
+  std::vector<FastItem> items;
+  make_leaves(d, L, direct, bb, items);
+  if (groups.empty() && items.size() == 1) return items[0].ref;  // a plain leaf group: no node of its own
+  for (uint32_t c : groups) {
+    FastItem it;
+    std::memcpy(it.bb, d->node_bbox + (size_t)c * 6, sizeof(it.bb));
+    it.ref = build_group(d, L, c, depth + 1);
+    if (!L.error.empty()) return RT_FREF_NONE;
+    items.push_back(it);
+  }
+  if (items.empty()) return RT_FREF_NONE;  // empty group
+  if (items.size() > 2 && depth + items.size() > L.depth) L.depth = depth + (uint32_t)items.size();
+  return fold_items(L, items, 0, bb);
+}
+
+bool build_fast_layout(const rt_scene_desc* d, FastLayout& L) {
+  assign_ranks(d, L.prim_rank);
+  L.prim_tri.assign(d->n_prims, RT_NONE);
+  L.nodes.reserve((size_t)d->n_nodes + 2);
+  L.nodes.emplace_back();  // node 0: the synthetic root
+  uint32_t root = build_group(d, L, 0, 1);
+  if (!L.error.empty()) return false;
+  DevNode n;
+  std::memset(&n, 0, sizeof(n));
+  std::memcpy(n.bb[0], d->node_bbox, sizeof(n.bb[0]));
+  n.ref[0] = root;
+  n.ref[1] = RT_FREF_NONE;
+  L.nodes[0] = n;
+  // triangles outside triangle-only leaves (mixed leaves, CSG operands) still need a slot in the triangle tables
+  for (uint32_t i = 0; i < d->n_prims; i++) {
+    uint8_t sh = d->prim_shape[i];
+    if ((sh == RT_SHAPE_TRIANGLE || sh == RT_SHAPE_SMOOTH_TRIANGLE) && L.prim_tri[i] == RT_NONE) L.prim_tri[i] = L.n_dev_tris++;
+  }
+  if (L.nodes.size() > RT_FREF_INDEX_MASK || L.n_dev_tris > RT_FREF_INDEX_MASK || L.leaf_ref.size() > RT_FREF_INDEX_MASK) {
+    L.error = "scene too large for 24-bit node/triangle indices";
+    return false;
+  }
+  return true;
 }
 
 int validate(const rt_scene_desc* d) {
@@ -308,12 +501,17 @@ int launch_render(const rt_scene* scene, const rt_camera* cam, const rt_options*
   }
   if (n_owned) {
     DevOptions dopt = dev_options(opt);
-    if (stats)
-      hipLaunchKernelGGL(render_tiles_kernel<true>, dim3(n_owned), dim3(64), 0, stream, scene->dev, *cam, dopt, part, n_parts,
-                         tiles_x, n_owned, packed, d_out, scene->d_stats, scene->d_overflow);
-    else
-      hipLaunchKernelGGL(render_tiles_kernel<false>, dim3(n_owned), dim3(64), 0, stream, scene->dev, *cam, dopt, part, n_parts,
-                         tiles_x, n_owned, packed, d_out, scene->d_stats, scene->d_overflow);
+#define RT_LAUNCH_TILES(STATS, REFORDER)                                                                                     \
+  hipLaunchKernelGGL((render_tiles_kernel<STATS, REFORDER>), dim3(n_owned), dim3(64), 0, stream, scene->dev, *cam, dopt, part, \
+                     n_parts, tiles_x, n_owned, packed, d_out, scene->d_stats, scene->d_overflow)
+    if (opt->reference_order) {
+      if (stats) RT_LAUNCH_TILES(true, true);
+      else RT_LAUNCH_TILES(false, true);
+    } else {
+      if (stats) RT_LAUNCH_TILES(true, false);
+      else RT_LAUNCH_TILES(false, false);
+    }
+#undef RT_LAUNCH_TILES
     HIP_TRY(hipGetLastError());
   }
   if (stats) {
@@ -338,6 +536,8 @@ int launch_render(const rt_scene* scene, const rt_camera* cam, const rt_options*
     stats->hits = h[7];
     stats->hit_bytes = h[8];
     stats->overflow_pixels = h[9];
+    stats->wave_steps = h[10];
+    stats->lane_steps = h[11];
     stats->ms_kernel = ms;
     if (ovf) return fail(RT_ERR_OVERFLOW, "a per-ray bounded list (BVH stack or CSG hit list) overflowed on the device");
   }
@@ -389,18 +589,48 @@ int rt_scene_create(const rt_scene_desc* d, rt_scene** out) {
     e.ref = d->child_ref[i];
     if ((e.ref >> RT_REF_KIND_SHIFT) == RT_REF_NODE) fill_node_fields(e, e.ref & RT_REF_INDEX_MASK);
   }
-  std::vector<uint4> prim_info(d->n_prims);
-  for (uint32_t i = 0; i < d->n_prims; i++) prim_info[i] = make_uint4(d->prim_shape[i], d->prim_material[i], d->prim_xform[i], d->prim_geom[i]);
-  std::vector<double> tri_isect((size_t)d->n_tris * 9), tri_norm((size_t)d->n_tris * 9);
-  for (size_t i = 0; i < d->n_tris; i++)
-    for (int k = 0; k < 3; k++) {
-      tri_isect[i * 9 + k] = d->tri_p1[i * 3 + k];
-      tri_isect[i * 9 + 3 + k] = d->tri_e1[i * 3 + k];
-      tri_isect[i * 9 + 6 + k] = d->tri_e2[i * 3 + k];
-      tri_norm[i * 9 + k] = d->tri_n1[i * 3 + k];
-      tri_norm[i * 9 + 3 + k] = d->tri_n2[i * 3 + k];
-      tri_norm[i * 9 + 6 + k] = d->tri_n3[i * 3 + k];
+  FastLayout L;
+  if (!build_fast_layout(d, L)) return fail(RT_ERR_UNSUPPORTED, L.error);
+  {  // near-child-first traversal pushes at most one sibling per level: the stack never exceeds the node depth
+    uint32_t deepest = 0;
+    std::vector<std::pair<uint32_t, uint32_t>> st{{0u, 1u}};
+    while (!st.empty()) {
+      auto [node, depth] = st.back();
+      st.pop_back();
+      if (depth > deepest) deepest = depth;
+      for (int c = 0; c < 2; c++) {
+        uint32_t r = L.nodes[node].ref[c];
+        if (r != RT_FREF_NONE && (r >> RT_FREF_KIND_SHIFT) == RT_FREF_INNER) st.push_back({r & RT_FREF_INDEX_MASK, depth + 1});
+      }
     }
+    if (deepest > RT_FAST_STACK_MAX)
+      return fail(RT_ERR_UNSUPPORTED, "the BVH is " + std::to_string(deepest) + " nodes deep; the device traversal stack holds " +
+                                          std::to_string(RT_FAST_STACK_MAX));
+  }
+  std::vector<uint4> prim_info(d->n_prims);
+  for (uint32_t i = 0; i < d->n_prims; i++) {
+    bool tri = d->prim_shape[i] == RT_SHAPE_TRIANGLE || d->prim_shape[i] == RT_SHAPE_SMOOTH_TRIANGLE;
+    prim_info[i] = make_uint4(d->prim_shape[i], d->prim_material[i], d->prim_xform[i], tri ? L.prim_tri[i] : d->prim_geom[i]);
+  }
+  // triangle tables in leaf order: [slot][RT_TRI_STRIDE] p1, e1, e2, prim;  [slot][9] n1, n2, n3
+  std::vector<double> tri_isect((size_t)L.n_dev_tris * RT_TRI_STRIDE), tri_norm((size_t)L.n_dev_tris * 9);
+  for (uint32_t i = 0; i < d->n_prims; i++) {
+    uint32_t slot = L.prim_tri[i];
+    if (slot == RT_NONE) continue;
+    size_t src = d->prim_geom[i];
+    double* ti = tri_isect.data() + (size_t)slot * RT_TRI_STRIDE;
+    double* tn = tri_norm.data() + (size_t)slot * 9;
+    for (int k = 0; k < 3; k++) {
+      ti[k] = d->tri_p1[src * 3 + k];
+      ti[3 + k] = d->tri_e1[src * 3 + k];
+      ti[6 + k] = d->tri_e2[src * 3 + k];
+      tn[k] = d->tri_n1[src * 3 + k];
+      tn[3 + k] = d->tri_n2[src * 3 + k];
+      tn[6 + k] = d->tri_n3[src * 3 + k];
+    }
+    uint64_t bits = i;
+    std::memcpy(ti + 9, &bits, sizeof(bits));
+  }
   std::vector<double> quadric((size_t)d->n_quadrics * 2);
   for (size_t i = 0; i < d->n_quadrics; i++) {
     quadric[i * 2] = d->quadric_y_min[i];
@@ -423,6 +653,9 @@ int rt_scene_create(const rt_scene_desc* d, rt_scene** out) {
     std::vector<T> _v((ptr), (ptr) + (size_t)(n));     \
     UP(_v, field);                                     \
   } while (0)
+  UP(L.nodes, nodes);
+  UP(L.leaf_ref, leaf_ref);
+  UP(L.prim_rank, prim_rank);
   UP(entries, entries);
   UP(prim_info, prim_info);
   UPA(uint32_t, d->prim_csg_left, d->n_prims, prim_csg_left);
@@ -520,8 +753,12 @@ int rt_trace_rays(const rt_scene* scene, const rt_options* options, uint32_t n, 
       rc = fail(RT_ERR_DEVICE, "upload of rays failed");
       break;
     }
-    hipLaunchKernelGGL(trace_rays_kernel, dim3((n + 63) / 64), dim3(64), 0, 0, scene->dev, dev_options(options), n, d_o, d_d, d_c,
-                       scene->d_overflow);
+    if (options->reference_order)
+      hipLaunchKernelGGL(trace_rays_kernel<true>, dim3((n + 63) / 64), dim3(64), 0, 0, scene->dev, dev_options(options), n, d_o, d_d,
+                         d_c, scene->d_overflow);
+    else
+      hipLaunchKernelGGL(trace_rays_kernel<false>, dim3((n + 63) / 64), dim3(64), 0, 0, scene->dev, dev_options(options), n, d_o, d_d,
+                         d_c, scene->d_overflow);
     uint32_t ovf = 0;
     if (hipDeviceSynchronize() != hipSuccess || hipMemcpy(out_rgb, d_c, bytes, hipMemcpyDeviceToHost) != hipSuccess ||
         hipMemcpy(&ovf, scene->d_overflow, sizeof(ovf), hipMemcpyDeviceToHost) != hipSuccess) {

@@ -22,10 +22,14 @@ for p in sorted(glob.glob(G + '/scenes/images/*/*.yml')) + sorted(glob.glob(G + 
     fs = rs.builder.flatten()
     t0 = time.time(); gpu, st = R.render(fs, rs.camera, rs.options()); t1 = time.time()
     cpu, cst = O.render(fs, rs.camera, rs.options()); t2 = time.time()
+    ropt = rs.options(); ropt.reference_order = 1
+    rgpu, rst = R.render(fs, rs.camera, ropt)
     d = np.abs(gpu - cpu)
     gu, cu = O.quantize(gpu), O.quantize(cpu)
     du = np.abs(gu.astype(int) - cu.astype(int)).max(axis=2)
     msg = f'{rel:36s} f64 maxabs {d.max():.3e} exact {(d.max(axis=2)==0).mean()*100:8.4f}%  u8 equal {(du==0).mean()*100:8.4f}% >1LSB {(du>1).sum()}  gpu {st["ms_kernel"]:.1f}ms cpu {(t2-t1)*1e3:.0f}ms'
+    msg += f'  reforder-vs-fast maxabs {np.abs(rgpu - gpu).max():.2e} ({rst["ms_kernel"]:.1f}ms)  simd {st["lane_steps"] / max(1, 64 * st["wave_steps"]):.2f}'
+    st = rst
     rays = ('rays_primary','rays_shadow','rays_reflect','rays_refract','node_visits','tri_tests','prim_tests')
     same = all(st[k] == cst[k] for k in rays)
     msg += '  counters ' + ('same' if same else 'DIFF ' + str({k:(st[k],cst[k]) for k in rays if st[k]!=cst[k]}))
