@@ -178,6 +178,8 @@ typedef struct rt_stats {
   uint64_t overflow_pixels;
   uint64_t wave_steps;  /* production traversal only: wavefront-level traversal steps ... */
   uint64_t lane_steps;  /* ... and the lanes active in them (lane_steps / (64 * wave_steps) = SIMD utilisation) */
+  uint64_t rays_retraced; /* production traversal only: rays whose hit was settled by a reference-order walk because two
+                             surfaces coincide within 1e-10 (see DESIGN.md "Ties") */
   double ms_upload, ms_kernel, ms_download;
 } rt_stats;
 

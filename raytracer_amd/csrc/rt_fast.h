@@ -18,7 +18,7 @@
 //    the reference collects on the same walk for the refractive-index containers (intersection.rs:258-302), are
 //    collected by a second walk over the boxes behind the origin, and only when the hit is transparent.
 #pragma once
-#include "rt_shading.h"
+#include "rt_reforder.h"
 
 namespace fast {
 
@@ -33,6 +33,7 @@ enum { M_CLOSEST = 0, M_SHADOW = 1, M_CONTAINERS = 2 };
 struct Trav {
   d3 o, d, dinv;
   double limit;   // closest: t of the best hit so far; shadow: distance to the light; containers: 0 (only boxes entered at t <= 0)
+  double t2;      // closest: smallest t of an intersection with any OTHER primitive than the hit (the runner-up)
   double a, b;    // closest: u, v of the hit; shadow: a = accumulated intensity; containers: largest negative t of the two innermost containers
   uint32_t p, q;  // closest: p = hit primitive; containers: the two innermost containers
   uint32_t h;     // containers: the primitive that was hit (closest pass)
@@ -53,6 +54,7 @@ __device__ __forceinline__ void trav_start(Trav& T, d3 o, d3 d, uint32_t mode, d
   if (mode == M_CLOSEST) {
     T.p = RT_NONE;
     T.a = T.b = -INFINITY;
+    T.t2 = INFINITY;
   } else if (mode == M_SHADOW) {
     T.a = 0.;
   } else {
@@ -72,6 +74,7 @@ __device__ __forceinline__ void add_roots(const DevScene& s, Trav& T, uint32_t p
       if (!sign_positive(t)) continue;
       bool take = t < T.limit;
       if (!take && t == T.limit && T.p != RT_NONE && T.p != prim) take = s.prim_rank[prim] < s.prim_rank[T.p];
+      if (T.p != prim) T.t2 = fmin(T.t2, take ? T.limit : t);  // the dethroned hit, or this rejected one
       if (take) {
         T.limit = t;
         T.p = prim;
@@ -164,6 +167,15 @@ __device__ __forceinline__ bool box_times(const double* __restrict__ bb, d3 o, d
   return !(tmin > tmax);
 }
 
+// Where the reference can differ from "smallest t, ties to the smallest rank": it skips a popped group when
+// t_enter >= closest t so far (group.rs:182).  A primitive lying ON a face of its group's box has t within rounding of
+// that t_enter, so when a SECOND surface coincides with it (dragons.yml: the glass cubes stand on the pedestal caps) the
+// reference may never test the nearer of the two.  Such a ray is recognised by a runner-up intersection within
+// RT_TIE_WINDOW of the hit and is re-traced in the reference's own order (reforder::traverse); for every other ray the
+// candidate sets are identical and so is the hit.  Boxes are therefore kept while they are entered within the window.
+#define RT_TIE_WINDOW 1.0e-10
+__device__ __forceinline__ double near_limit(double limit) { return limit + RT_TIE_WINDOW * fmax(1., limit); }
+
 __device__ __forceinline__ void stack_push(Trav& T, uint2* lds, uint2* ovf, uint32_t ref, double t, Counters& cnt) {
   uint2 e = make_uint2(ref, __float_as_uint(__double2float_rd(t)));
   if (T.sp < RT_LDS_STACK) lds[T.sp * 64] = e;
@@ -180,7 +192,7 @@ __device__ __forceinline__ uint32_t stack_pop(Trav& T, const uint2* lds, const u
     T.sp--;
     uint2 e = lds[(T.sp < RT_LDS_STACK ? T.sp : RT_LDS_STACK - 1) * 64];
     if (T.sp >= RT_LDS_STACK) e = ovf[T.sp - RT_LDS_STACK];
-    if (!((double)__uint_as_float(e.y) > T.limit)) return e.x;  // still able to hold an accepted intersection
+    if (!((double)__uint_as_float(e.y) > near_limit(T.limit))) return e.x;  // still able to hold an accepted intersection
   }
   return RT_FREF_NONE;
 }
@@ -208,9 +220,11 @@ __device__ __forceinline__ void trav_run(const DevScene& s, Trav& T, uint2* lds,
       bool h0 = box_times(bb0, T.o, T.dinv, t0, x0);
       bool h1 = box_times(bb1, T.o, T.dinv, t1, x1);
       if (STATS) cnt.node_visits += 1u + (r1 != RT_FREF_NONE ? 1u : 0u);
-      // a box can hold an accepted intersection only if it is entered no later than the limit ...
-      h0 = h0 && !(t0 > T.limit) && r0 != RT_FREF_NONE;
-      h1 = h1 && !(t1 > T.limit) && r1 != RT_FREF_NONE;
+      // a box can hold an accepted intersection only if it is entered no later than the limit (plus the window in
+      // which a runner-up must still be seen, see near_limit) ...
+      double lim = near_limit(T.limit);
+      h0 = h0 && !(t0 > lim) && r0 != RT_FREF_NONE;
+      h1 = h1 && !(t1 > lim) && r1 != RT_FREF_NONE;
       if (T.mode != M_CONTAINERS) {  // ... and, for t >= 0 intersections, is not entirely behind the origin
         h0 = h0 && !(x0 < 0.);
         h1 = h1 && !(x1 < 0.);
@@ -361,6 +375,19 @@ __device__ __forceinline__ void run_machine(const DevScene& s, const DevOptions&
     do {
       Frame& F = frames[depth];
       if (pc == PC_AFTER_CLOSEST) {
+#ifdef RT_EMU_TRACE
+        printf("fast  depth %d hit prim %u t %.17g o %.17g %.17g %.17g d %.17g %.17g %.17g\n", depth, T.p, T.limit, T.o.x, T.o.y, T.o.z, T.d.x, T.d.y, T.d.z);
+#endif
+        if (T.p != RT_NONE && T.t2 <= near_limit(T.limit)) {  // coincident surfaces: settle the hit in the reference's order
+          reforder::Coll c;
+          reforder::coll_init_closest(c);
+          reforder::traverse<reforder::MODE_CLOSEST, STATS>(s, T.o, T.d, c, cnt);
+          T.p = c.hit_prim;
+          T.limit = c.limit;
+          T.a = c.hu;
+          T.b = c.hv;
+          if (STATS) cnt.retraced++;
+        }
         if (T.p == RT_NONE) {  // miss: black (integrator.rs:62-65)
           ret = mk3(0., 0., 0.);
           pc = PC_RETURN;
@@ -388,6 +415,9 @@ __device__ __forceinline__ void run_machine(const DevScene& s, const DevOptions&
           }
         }
       }
+#ifdef RT_EMU_TRACE
+      if (pc == PC_AFTER_CONTAINERS) printf("fast  containers pa %u ta %.17g pb %u tb %.17g flag %u\n", T.p, T.a, T.q, T.b, T.flag);
+#endif
       if (pc == PC_AFTER_CONTAINERS) {  // get_refractive (intersection.rs:258-302)
         hprim = F.prim;
         ht = F.t;

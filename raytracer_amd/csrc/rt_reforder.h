@@ -242,6 +242,9 @@ __device__ d3 trace(const DevScene& s, const DevOptions& opt, d3 ro, d3 rd, Coun
       Coll c;
       coll_init_closest(c);
       traverse<MODE_CLOSEST, STATS>(s, o, d, c, cnt);
+#ifdef RT_EMU_TRACE
+      printf("ref   depth %d hit prim %u t %.17g o %.17g %.17g %.17g d %.17g %.17g %.17g | pa %u ta %.17g pb %u tb %.17g odd %d\n", depth, c.hit_prim, c.limit, o.x, o.y, o.z, d.x, d.y, d.z, c.pa, c.ta, c.pb, c.tb, (int)c.hit_neg_odd);
+#endif
       if (c.hit_prim == RT_NONE) {
         ret = mk3(0., 0., 0.);
         finished = true;

@@ -13,12 +13,11 @@
 #include <vector>
 
 #include "rt_fast.h"
-#include "rt_reforder.h"
 
 // ---------------------------------------------------------------------------------------------
 // kernels
 // ---------------------------------------------------------------------------------------------
-#define RT_N_COUNTERS 12
+#define RT_N_COUNTERS 13
 #ifndef RT_WAVES_PER_EU
 #define RT_WAVES_PER_EU 4  // waves per SIMD the register allocator must leave room for (128 VGPRs)
 #endif
@@ -28,7 +27,8 @@ __device__ __forceinline__ void flush_counters(const Counters& c, unsigned long 
   if (c.overflow) atomicOr(overflow_flag, 1u);
   if (!STATS) return;
   uint32_t v[RT_N_COUNTERS] = {c.rays_primary, c.rays_shadow, c.rays_reflect, c.rays_refract, c.node_visits, c.tri_tests,
-                               c.prim_tests,   c.hits,        c.hit_bytes,    c.overflow,     c.wave_steps,  c.lane_steps};
+                               c.prim_tests,   c.hits,        c.hit_bytes,    c.overflow,     c.wave_steps,  c.lane_steps,
+                               c.retraced};
   for (int k = 0; k < RT_N_COUNTERS; k++) {
     unsigned long long x = v[k];
     for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
@@ -58,7 +58,7 @@ __global__ __launch_bounds__(64, REFORDER ? 2 : RT_WAVES_PER_EU) void render_til
   uint32_t lane = threadIdx.x;
   uint32_t px = (tile % tiles_x) * RT_TILE_DIM + (lane & 7u);
   uint32_t py = (tile / tiles_x) * RT_TILE_DIM + (lane >> 3);
-  Counters cnt = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  Counters cnt = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   bool inside = px < cam.width && py < cam.height;
   d3 color = mk3(0., 0., 0.);
   if (REFORDER) {
@@ -143,7 +143,7 @@ __global__ __launch_bounds__(64, REFORDER ? 2 : RT_WAVES_PER_EU) void trace_rays
                                                                           uint32_t* overflow_flag) {
   __shared__ uint2 lds_stack[RT_LDS_STACK * 64];
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  Counters cnt = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  Counters cnt = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   bool valid = i < n;
   d3 o = mk3(0., 0., 0.), d = mk3(0., 0., 1.), c = mk3(0., 0., 0.);
   if (valid) {
@@ -538,6 +538,7 @@ int launch_render(const rt_scene* scene, const rt_camera* cam, const rt_options*
     stats->overflow_pixels = h[9];
     stats->wave_steps = h[10];
     stats->lane_steps = h[11];
+    stats->rays_retraced = h[12];
     stats->ms_kernel = ms;
     if (ovf) return fail(RT_ERR_OVERFLOW, "a per-ray bounded list (BVH stack or CSG hit list) overflowed on the device");
   }

@@ -257,3 +257,60 @@ def test_quantize_device_matches_host():
     got = out.cpu().numpy()
     assert np.array_equal(got, O.quantize(v)) and np.array_equal(got, R.as_u8_rgb(v))
     assert list(got[:4]) == [255, 128, 0, 0]
+
+
+# ---- production traversal vs reference-order traversal (rt_options.reference_order) --------------------
+def _ref_order(opt):
+    o = type(opt)()
+    C.memmove(C.byref(o), C.byref(opt), C.sizeof(opt))
+    o.reference_order = 1
+    return o
+
+
+@pytest.mark.parametrize("name", ["images/" + n for n in IMAGES] + ["animations/general/" + n for n in ANIMS])
+def test_reference_order_mode_matches_production_and_oracle(name):
+    """The validation mode walks the BVH exactly like ObjectGroup::intersect_iter (group.rs:171-201); the production
+    traversal (near child first, boxes behind the origin culled, ties by visit rank) must give the same pixels, and the
+    validation mode's node/triangle counts must be the oracle's for shadow-free work (same algorithm, same order)."""
+    kind, rel = name.split("/", 1)
+    rs = Y.load_scene(scene_path(kind, rel), width=160, height=160, depth=5, supersampling_level=2)
+    flat, cam, opt = rs.builder.flatten(), rs.camera, rs.options()
+    fast, st_fast = R.render(flat, cam, opt)
+    ref, st_ref = R.render(flat, cam, _ref_order(opt))
+    assert float(np.abs(fast - ref).max()) < 1e-12
+    assert np.array_equal(O.quantize(fast), O.quantize(ref))
+    for k in ("rays_primary", "rays_shadow", "rays_reflect", "rays_refract", "hits"):
+        assert st_fast[k] == st_ref[k]
+    check_against_oracle(flat, cam, opt, gpu=ref)
+
+
+def test_reference_order_rays():
+    rs = Y.load_scene(scene_path("images", "chapters/refractions"))
+    flat = rs.builder.flatten()
+    rng = np.random.default_rng(99)
+    n = 2048
+    origins = rng.uniform(-4, 4, (n, 3)) + [0., 2., 0.]
+    dirs = rng.normal(size=(n, 3))
+    dirs /= np.linalg.norm(dirs, axis=1, keepdims=True)
+    opt = S.make_options(1, 5, True)
+    sc = R.DeviceScene(flat)
+    a = sc.trace_rays(opt, origins, dirs)
+    b = sc.trace_rays(_ref_order(opt), origins, dirs)
+    assert float(np.abs(a - b).max()) < 1e-12
+
+
+def test_full_size_4k_production_equals_reference_order():
+    """BASELINE config 5 at full size (dragons.yml 3840x2160, supersampling 4, depth 5): the production traversal and the
+    reference-order traversal agree on every f64 pixel; the image is not trivially black."""
+    torch = _torch()
+    rs = Y.load_scene(scene_path("images", "general/dragons"), width=3840, height=2160, depth=5, supersampling_level=4)
+    cam, opt = rs.camera, rs.options()
+    scene = R.DeviceScene(rs.builder.flatten())
+    a = torch.empty((cam.height, cam.width, 3), dtype=torch.float64, device="cuda")
+    b = torch.empty_like(a)
+    st = scene.render_device(cam, opt, a.data_ptr(), want_stats=True)
+    scene.render_device(cam, _ref_order(opt), b.data_ptr())
+    torch.cuda.synchronize()
+    assert st["overflow_pixels"] == 0 and st["rays_primary"] == 3840 * 2160 * 16
+    assert float((a - b).abs().max().item()) < 1e-12
+    assert float((a > 0).double().mean().item()) > 0.05
