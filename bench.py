@@ -199,7 +199,8 @@ def main():
         value = rays * args.steps / t_max / 1e6
         # roofline of the dominant kernel (render_tiles_kernel) on rank 0
         k_ms = float(allv[0, len(keys) + 1])
-        k_bytes = float(allv[0, len(keys) + 2])
+        k_bytes_ref = float(allv[0, len(keys) + 2])   # reference-order counts
+        k_bytes = float(allv[0, len(keys) + 3])       # this launch's own counts
         achieved = k_bytes / (k_ms * 1e-3) / 1e9
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
@@ -220,12 +221,15 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "render_tiles_kernel<false, false>", "kernel_ms": k_ms, "algorithmic_bytes_per_launch": k_bytes,
-                         "bytes_fetched_by_this_traversal": float(allv[0, len(keys) + 3]),
+                         "algorithmic_bytes_reference_order": k_bytes_ref,
+                         "achieved_reference_order_equivalent": k_bytes_ref / (k_ms * 1e-3) / 1e9,
                          "simd_utilisation": float(allv[:, len(keys) + 4].sum() / max(1.0, 64.0 * float(allv[:, len(keys) + 5].sum()))),
-                         "note": "algorithmic bytes = SURVEY.md §8d constants x the node/triangle/primitive/hit counts of the "
-                                 "reference's own traversal order (counted on-device in reference-order mode); the production "
-                                 "traversal visits fewer nodes for the same pixels (bytes_fetched_by_this_traversal); the scene "
-                                 "working set (~40 MB) lives in L2/Infinity Cache, so HBM traffic is far below either figure"},
+                         "note": "algorithmic bytes = SURVEY.md §8d per-unit constants (52 B per box test, 72 B per triangle "
+                                 "test, 113 B per analytic-primitive test, per-hit shading bytes, 24 B per pixel) x the units "
+                                 "THIS launch processes (counted by an identical statistics launch); the same constants x the "
+                                 "counts of the reference's own visiting order (reference-order mode, more box tests for the "
+                                 "same pixels) are given as *_reference_order.  The scene working set (~40 MB) is served from "
+                                 "L2 / Infinity Cache, so real HBM traffic (`traffic`, PMC) is far below either figure"},
             "parity": {"max_abs_diff_vs_reference_order_render": float(allv[:, len(keys) + 6].max()),
                        "note": "full-size cross-check: production traversal vs reference-order traversal, f64 pixels"},
         }

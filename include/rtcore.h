@@ -180,6 +180,8 @@ typedef struct rt_stats {
   uint64_t lane_steps;  /* ... and the lanes active in them (lane_steps / (64 * wave_steps) = SIMD utilisation) */
   uint64_t rays_retraced; /* production traversal only: rays whose hit was settled by a reference-order walk because two
                              surfaces coincide within 1e-10 (see DESIGN.md "Ties") */
+  uint64_t clocks_traversal, clocks_machine; /* production traversal, statistics launches only: shader clocks summed over
+                             lanes spent in the traversal loop / in the shading state machine */
   double ms_upload, ms_kernel, ms_download;
 } rt_stats;
 

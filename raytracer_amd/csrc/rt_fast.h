@@ -191,7 +191,11 @@ __device__ __forceinline__ uint32_t stack_pop(Trav& T, const uint2* lds, const u
   while (T.sp > 0) {
     T.sp--;
     uint2 e = lds[(T.sp < RT_LDS_STACK ? T.sp : RT_LDS_STACK - 1) * 64];
-    if (T.sp >= RT_LDS_STACK) e = ovf[T.sp - RT_LDS_STACK];
+    if (T.sp >= RT_LDS_STACK) {  // volatile: keeps this a scratch load (otherwise the two loads are merged into one flat load
+      const volatile uint2* v = ovf;  // through a selected pointer, which waits on both memory counters)
+      e.x = v[T.sp - RT_LDS_STACK].x;
+      e.y = v[T.sp - RT_LDS_STACK].y;
+    }
     if (!((double)__uint_as_float(e.y) > near_limit(T.limit))) return e.x;  // still able to hold an accepted intersection
   }
   return RT_FREF_NONE;
@@ -205,8 +209,7 @@ __device__ __forceinline__ void count_step(Counters& cnt) {  // statistics build
 
 // Runs the lane's traversal to completion (lanes whose T.cur is RT_FREF_NONE have nothing to do).
 template <bool STATS>
-__device__ __forceinline__ void trav_run(const DevScene& s, Trav& T, uint2* lds, Counters& cnt) {
-  uint2 ovf[RT_OVF_STACK];
+__device__ __forceinline__ void trav_run(const DevScene& s, Trav& T, uint2* lds, uint2* ovf, Counters& cnt) {
   while (T.cur != RT_FREF_NONE) {
     // ---- inner nodes: descend until this lane holds a leaf (or runs out of work) ----
     while ((T.cur >> RT_FREF_KIND_SHIFT) == RT_FREF_INNER) {
@@ -342,6 +345,8 @@ struct OneRay {
   __device__ __forceinline__ void add(d3 c) { color = c; }
 };
 
+__device__ __forceinline__ unsigned long long wave_clock() { return (unsigned long long)clock64(); }  // statistics builds only
+
 template <bool STATS, class Rays>
 __device__ __forceinline__ void run_machine(const DevScene& s, const DevOptions& opt, Rays& rays, bool lane_has_work, uint2* lds,
                                             Counters& cnt) {
@@ -363,8 +368,15 @@ __device__ __forceinline__ void run_machine(const DevScene& s, const DevOptions&
       finished = true;
     }
   }
+  uint2 ovf[RT_OVF_STACK];
   while (__builtin_amdgcn_ballot_w64(!finished) != 0ull) {
-    trav_run<STATS>(s, T, lds, cnt);
+    // Lock step: every lane finishes its traversal before any lane advances.  (Letting idle lanes fetch their next ray
+    // while stragglers are still traversing was measured 1.8-2.3x SLOWER on the dragons frame: the state machine then
+    // runs many more times with few lanes each, and the fresh rays diverge from the stragglers.)
+    unsigned long long c0 = STATS ? wave_clock() : 0ull;
+    trav_run<STATS>(s, T, lds, ovf, cnt);
+    unsigned long long c1 = STATS ? wave_clock() : 0ull;
+    if (STATS && !finished) cnt.cyc_trav += (uint32_t)((c1 - c0) >> 6);
     if (finished) continue;
     // ---- the lane's traversal is complete: advance its state machine to the next ray ----
     uint32_t pc = frames[depth].pc;
@@ -571,6 +583,7 @@ __device__ __forceinline__ void run_machine(const DevScene& s, const DevOptions&
         }
       }
     } while (pc != PC_TRACE && pc != PC_DONE);
+    if (STATS) cnt.cyc_adv += (uint32_t)((wave_clock() - c1) >> 6);
   }
 }
 

@@ -17,9 +17,9 @@
 // ---------------------------------------------------------------------------------------------
 // kernels
 // ---------------------------------------------------------------------------------------------
-#define RT_N_COUNTERS 13
+#define RT_N_COUNTERS 15
 #ifndef RT_WAVES_PER_EU
-#define RT_WAVES_PER_EU 4  // waves per SIMD the register allocator must leave room for (128 VGPRs)
+#define RT_WAVES_PER_EU 2  // waves per SIMD the register allocator must leave room for (256 VGPRs: no spills; measured best)
 #endif
 
 template <bool STATS>
@@ -28,7 +28,7 @@ __device__ __forceinline__ void flush_counters(const Counters& c, unsigned long 
   if (!STATS) return;
   uint32_t v[RT_N_COUNTERS] = {c.rays_primary, c.rays_shadow, c.rays_reflect, c.rays_refract, c.node_visits, c.tri_tests,
                                c.prim_tests,   c.hits,        c.hit_bytes,    c.overflow,     c.wave_steps,  c.lane_steps,
-                               c.retraced};
+                               c.retraced,     c.cyc_trav,    c.cyc_adv};
   for (int k = 0; k < RT_N_COUNTERS; k++) {
     unsigned long long x = v[k];
     for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
@@ -36,13 +36,40 @@ __device__ __forceinline__ void flush_counters(const Counters& c, unsigned long 
   }
 }
 
-// XCD-aware tile order: consecutive workgroup ids are dealt round-robin over the 8 XCDs (each with its own L2),
-// so give every XCD a contiguous run of tiles (neighbouring tiles walk the same BVH subtrees).  Bijective for
-// any n (cdna_hip_programming.md T1).
-__device__ __forceinline__ uint32_t xcd_remap(uint32_t bid, uint32_t n) {
-  uint32_t q = n / 8, r = n % 8, xcd = bid % 8, k = bid / 8;
-  uint32_t base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
-  return base + k;
+// XCD-aware tile order.  Consecutive workgroup ids are dealt round-robin over the 8 XCDs (each with its own L2), so
+// workgroup id -> position in the tile order is chosen such that every XCD receives whole groups of RT_XCD_GROUP
+// consecutive positions (one 16x16-tile block of the image: neighbouring tiles walk the same BVH subtrees, so they should
+// share an L2), and the groups are dealt to the XCDs round-robin.  (Giving each XCD one contiguous eighth of the frame
+// instead left the XCDs that own empty sky idle: 1.45 resident waves per SIMD on average on the dragons frame.)
+// The grid is rounded up to a multiple of 8 * RT_XCD_GROUP; positions >= n are idle workgroups.
+#define RT_XCD_GROUP 256u
+__device__ __forceinline__ uint32_t xcd_remap(uint32_t bid) {
+  uint32_t xcd = bid % 8, k = bid / 8;
+  return ((k / RT_XCD_GROUP) * 8 + xcd) * RT_XCD_GROUP + k % RT_XCD_GROUP;
+}
+
+// Order in which an XCD walks its run of tiles: blocks of RT_BLOCK x RT_BLOCK tiles, row-major inside a block, so that the
+// tiles in flight on one XCD (32 CUs x a few waves) cover a compact patch of the image and share BVH subtrees in its L2.
+// Maps the j-th position of that order to the row-major cell index of a gx x gy grid (bijective, ragged edges included).
+#define RT_BLOCK 16u
+__device__ __forceinline__ uint32_t blocked_order(uint32_t j, uint32_t gx, uint32_t gy) {
+  uint32_t r = j / (RT_BLOCK * gx);             // block row
+  uint32_t hr = min(RT_BLOCK, gy - r * RT_BLOCK);  // its height
+  uint32_t jj = j - r * RT_BLOCK * gx;
+  uint32_t full = gx / RT_BLOCK;                // full-width blocks in a block row
+  uint32_t bc = jj / (hr * RT_BLOCK);
+  uint32_t cx, cy;
+  if (bc < full) {
+    uint32_t w = jj - bc * hr * RT_BLOCK;
+    cy = w / RT_BLOCK;
+    cx = bc * RT_BLOCK + w % RT_BLOCK;
+  } else {
+    uint32_t wl = gx - full * RT_BLOCK;  // width of the ragged last block (> 0 here)
+    uint32_t w = jj - full * hr * RT_BLOCK;
+    cy = w / wl;
+    cx = full * RT_BLOCK + w % wl;
+  }
+  return (r * RT_BLOCK + cy) * gx + cx;
 }
 
 // Renderer::color_at_pixel (renderer.rs:50-66) for one 8x8 tile per wavefront.
@@ -53,12 +80,17 @@ __global__ __launch_bounds__(64, REFORDER ? 2 : RT_WAVES_PER_EU) void render_til
                                                                             int packed, double* __restrict__ out,
                                                                             unsigned long long* stats, uint32_t* overflow_flag) {
   __shared__ uint2 lds_stack[RT_LDS_STACK * 64];
-  uint32_t k = xcd_remap(blockIdx.x, n_owned);
+  uint32_t k = xcd_remap(blockIdx.x);
+  if (k >= n_owned) return;
+  if (tiles_x % n_parts == 0) {  // this part's tiles form a regular (tiles_x / n_parts)-wide grid: walk it block by block
+    uint32_t gx = tiles_x / n_parts;
+    k = blocked_order(k, gx, n_owned / gx);
+  }
   uint32_t tile = k * n_parts + part;
   uint32_t lane = threadIdx.x;
   uint32_t px = (tile % tiles_x) * RT_TILE_DIM + (lane & 7u);
   uint32_t py = (tile / tiles_x) * RT_TILE_DIM + (lane >> 3);
-  Counters cnt = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  Counters cnt = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   bool inside = px < cam.width && py < cam.height;
   d3 color = mk3(0., 0., 0.);
   if (REFORDER) {
@@ -143,7 +175,7 @@ __global__ __launch_bounds__(64, REFORDER ? 2 : RT_WAVES_PER_EU) void trace_rays
                                                                           uint32_t* overflow_flag) {
   __shared__ uint2 lds_stack[RT_LDS_STACK * 64];
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  Counters cnt = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  Counters cnt = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   bool valid = i < n;
   d3 o = mk3(0., 0., 0.), d = mk3(0., 0., 1.), c = mk3(0., 0., 0.);
   if (valid) {
@@ -501,8 +533,9 @@ int launch_render(const rt_scene* scene, const rt_camera* cam, const rt_options*
   }
   if (n_owned) {
     DevOptions dopt = dev_options(opt);
+    uint32_t grid = (n_owned + 8 * RT_XCD_GROUP - 1) / (8 * RT_XCD_GROUP) * (8 * RT_XCD_GROUP);
 #define RT_LAUNCH_TILES(STATS, REFORDER)                                                                                     \
-  hipLaunchKernelGGL((render_tiles_kernel<STATS, REFORDER>), dim3(n_owned), dim3(64), 0, stream, scene->dev, *cam, dopt, part, \
+  hipLaunchKernelGGL((render_tiles_kernel<STATS, REFORDER>), dim3(grid), dim3(64), 0, stream, scene->dev, *cam, dopt, part, \
                      n_parts, tiles_x, n_owned, packed, d_out, scene->d_stats, scene->d_overflow)
     if (opt->reference_order) {
       if (stats) RT_LAUNCH_TILES(true, true);
@@ -539,6 +572,8 @@ int launch_render(const rt_scene* scene, const rt_camera* cam, const rt_options*
     stats->wave_steps = h[10];
     stats->lane_steps = h[11];
     stats->rays_retraced = h[12];
+    stats->clocks_traversal = h[13] * 64;
+    stats->clocks_machine = h[14] * 64;
     stats->ms_kernel = ms;
     if (ovf) return fail(RT_ERR_OVERFLOW, "a per-ray bounded list (BVH stack or CSG hit list) overflowed on the device");
   }

@@ -36,6 +36,7 @@ static inline float __double2float_rd(double d) {
   return f;
 }
 static inline unsigned long long __builtin_amdgcn_ballot_w64(bool b) { return b ? 1ull : 0ull; }
+static inline long long clock64() { return 0; }
 static inline int __ffsll(long long v) { return __builtin_ffsll(v); }
 template <class T> static inline T __shfl_down(T, int, int) { return T(0); }
 template <class T> static inline T atomicAdd(T* p, T v) { T o = *p; *p += v; return o; }
