@@ -165,7 +165,13 @@ typedef struct rt_options {
   uint32_t reference_order;  /* 0: production traversal (near child first, LDS stack).  1: visit the BVH exactly in the
                                 order of ObjectGroup::intersect_iter (group.rs:171-201): validation and counting mode —
                                 same pixels, slower; its node/triangle counts are the reference's algorithmic work */
+  uint32_t pipeline;         /* RT_PIPELINE_STREAM (0, production): rays streamed through trace / shade / combine kernels.
+                                RT_PIPELINE_SINGLE_KERNEL (1): one kernel holds a pixel's whole recursion (same pixels, bit
+                                for bit; kept for comparison and as the overflow fallback of the streamed pipeline).
+                                Ignored when reference_order = 1 */
 } rt_options;
+#define RT_PIPELINE_STREAM 0u
+#define RT_PIPELINE_SINGLE_KERNEL 1u
 
 #define RT_MAX_DEPTH 16u
 
@@ -182,6 +188,8 @@ typedef struct rt_stats {
                              surfaces coincide within 1e-10 (see DESIGN.md "Ties") */
   uint64_t clocks_traversal, clocks_machine; /* production traversal, statistics launches only: shader clocks summed over
                              lanes spent in the traversal loop / in the shading state machine */
+  uint64_t fallback_flags; /* streamed pipeline: times a ray or hit found its batch's queues full; the samples concerned were
+                              re-rendered by the single-kernel state machine (same pixels, slower).  0 in a well-sized batch */
   double ms_upload, ms_kernel, ms_download;
 } rt_stats;
 

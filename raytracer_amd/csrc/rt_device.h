@@ -56,11 +56,14 @@ __device__ __forceinline__ d3 mat_transposed_vector(const double* __restrict__ m
 // Device scene layout (built by rt_scene_create from rt_scene_desc; see DESIGN.md "Data layout in HBM")
 // ---------------------------------------------------------------------------------------------
 
-// --- fast path (rt_fast.h): binary nodes, 128 B, one dependent load per traversal step -----------
-// A node holds the boxes of BOTH children, so testing the two children of a node is one 128-B fetch and the
-// child references come with it.  Groups of the reference that are not "two sub-groups" are rewritten at scene
-// creation: a group of primitives becomes a LEAF reference in its parent (no node of its own); n-ary or mixed
-// groups become short chains of binary nodes whose synthetic boxes repeat the group's own box.
+// --- fast path (rt_fast.h): 4-wide nodes, 128 B (one cache line), one dependent fetch per traversal step --------
+// Traversal is bound by the latency of that dependent fetch (about one L2 miss per wavefront step), so a node holds the
+// boxes of up to FOUR children: the reference's binary tree with every other level folded away (the boxes of the folded
+// level are simply not tested), which halves the number of dependent fetches per ray.  The boxes are the reference's f64
+// boxes rounded OUTWARD to f32: a superset of each box, tested with the reference's f64 slab arithmetic, so no box is
+// culled that the exact box would keep.  Groups of the reference that are not "two sub-groups" are rewritten at scene
+// creation: a group of primitives becomes a LEAF reference in its parent (no node of its own); n-ary or mixed groups
+// become short chains of binary nodes (whose synthetic boxes repeat the group's own box) before the fold.
 #define RT_FREF_INNER 0u  // index = node
 #define RT_FREF_TRIS 1u   // index = first triangle of a run in tri_isect/tri_norm, count = run length
 #define RT_FREF_PRIMS 2u  // index = first entry of a run in leaf_ref (RT_REF_PRIM / RT_REF_CSG references)
@@ -73,10 +76,11 @@ __device__ __forceinline__ d3 mat_transposed_vector(const double* __restrict__ m
 #define RT_FREF_NONE 0xFFFFFFFFu  // kind EMPTY: nothing left to visit
 #define RT_MAKE_FREF(kind, count, index) (((uint32_t)(kind) << RT_FREF_KIND_SHIFT) | ((uint32_t)(count) << RT_FREF_COUNT_SHIFT) | (uint32_t)(index))
 
+#define RT_NODE_WIDTH 4
 struct __attribute__((aligned(128))) DevNode {
-  double bb[2][6];  // boxes of child 0 and child 1: min x,y,z, max x,y,z (bounding_box.rs:25-28), exact f64
-  uint32_t ref[2];  // RT_MAKE_FREF
-  uint32_t pad[2];
+  float bb[RT_NODE_WIDTH][6];   // child boxes: min x,y,z (rounded down), max x,y,z (rounded up) (bounding_box.rs:25-28)
+  uint32_t ref[RT_NODE_WIDTH];  // RT_MAKE_FREF; unused slots hold RT_FREF_NONE and come last
+  uint32_t pad[4];
 };
 
 // Triangles are stored in leaf order, RT_TRI_STRIDE doubles each (80 B, 16-B aligned): p1, e1, e2, then the

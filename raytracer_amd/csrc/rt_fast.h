@@ -22,12 +22,20 @@
 
 namespace fast {
 
+#ifndef RT_LDS_STACK
 #define RT_LDS_STACK 16                                   // per-lane stack entries in LDS (8 KB per wavefront)
+#endif
+#ifndef RT_OVF_STACK
 #define RT_OVF_STACK 48                                   // further entries in scratch
+#endif
 #define RT_FAST_STACK_MAX (RT_LDS_STACK + RT_OVF_STACK)  // validated against the tree depth at scene creation
 #define RT_FRAMES (RT_MAX_DEPTH + 1)
 
 enum { M_CLOSEST = 0, M_SHADOW = 1, M_CONTAINERS = 2 };
+
+// The set of modes a kernel's lanes can be in (bit m = mode m), so that a kernel which only ever traces shadow rays, or
+// never does, carries no code or registers for the other collectors.  MS_ALL: the mode is a per-lane run-time value.
+enum { MS_ALL = 7, MS_CLOSEST_CONTAINERS = 5, MS_SHADOW = 2 };
 
 // The ray being traversed and its collector (IntersectionCollector, intersection.rs:17-135, without the Vec).
 struct Trav {
@@ -64,11 +72,18 @@ __device__ __forceinline__ void trav_start(Trav& T, d3 o, d3 d, uint32_t mode, d
   }
 }
 
+template <int MS>
+__device__ __forceinline__ bool in_mode(const Trav& T, uint32_t m) {
+  if (!((MS >> m) & 1)) return false;
+  if (MS == (1 << m)) return true;
+  return T.mode == m;
+}
+
 // All roots of ONE primitive, in the order the reference add()s them (intersection.rs:65-109).
-template <bool STATS>
+template <bool STATS, int MS = MS_ALL>
 __device__ __forceinline__ void add_roots(const DevScene& s, Trav& T, uint32_t prim, uint32_t material, int n, const double* ts,
                                           double u, double v) {
-  if (T.mode == M_CLOSEST) {
+  if (in_mode<MS>(T, M_CLOSEST)) {
     for (int i = 0; i < n; i++) {
       double t = ts[i];
       if (!sign_positive(t)) continue;
@@ -82,7 +97,7 @@ __device__ __forceinline__ void add_roots(const DevScene& s, Trav& T, uint32_t p
         T.b = v;
       }
     }
-  } else if (T.mode == M_SHADOW) {
+  } else if (in_mode<MS>(T, M_SHADOW)) {
     double transparency = 0.;
     bool loaded = false;
     for (int i = 0; i < n; i++) {
@@ -128,11 +143,11 @@ __device__ __forceinline__ void add_roots(const DevScene& s, Trav& T, uint32_t p
 }
 
 // CsgObject::intersect (csg.rs:112-122): survivors go to the collector in ascending t.
-template <bool STATS>
+template <bool STATS, int MS = MS_ALL>
 __device__ __forceinline__ void add_csg(const DevScene& s, Trav& T, uint32_t csg_root, Counters& cnt) {
   CsgHit list[RT_CSG_LIST_MAX];
   int n = csg_survivors<STATS>(s, csg_root, T.o, T.d, T.dinv, list, cnt);
-  if (T.mode == M_CONTAINERS) {
+  if (in_mode<MS>(T, M_CONTAINERS)) {
     // negative-t survivors, aggregated per leaf object (they all come from this one call)
     for (int i = 0; i < n; i++) {
       if (sign_positive(list[i].t)) continue;
@@ -144,13 +159,13 @@ __device__ __forceinline__ void add_csg(const DevScene& s, Trav& T, uint32_t csg
       int k = 0;
       for (int j = i; j < n; j++)
         if (!sign_positive(list[j].t) && list[j].prim == list[i].prim) ts[k++] = list[j].t;
-      add_roots<STATS>(s, T, list[i].prim, 0, k, ts, 0., 0.);
+      add_roots<STATS, MS>(s, T, list[i].prim, 0, k, ts, 0., 0.);
     }
   } else {
     for (int i = 0; i < n; i++) {
       uint32_t prim = list[i].prim;
-      uint32_t material = T.mode == M_SHADOW ? s.prim_info[prim].y : 0u;
-      add_roots<STATS>(s, T, prim, material, 1, &list[i].t, list[i].u, list[i].v);
+      uint32_t material = in_mode<MS>(T, M_SHADOW) ? s.prim_info[prim].y : 0u;
+      add_roots<STATS, MS>(s, T, prim, material, 1, &list[i].t, list[i].u, list[i].v);
     }
   }
 }
@@ -176,8 +191,8 @@ __device__ __forceinline__ bool box_times(const double* __restrict__ bb, d3 o, d
 #define RT_TIE_WINDOW 1.0e-10
 __device__ __forceinline__ double near_limit(double limit) { return limit + RT_TIE_WINDOW * fmax(1., limit); }
 
-__device__ __forceinline__ void stack_push(Trav& T, uint2* lds, uint2* ovf, uint32_t ref, double t, Counters& cnt) {
-  uint2 e = make_uint2(ref, __float_as_uint(__double2float_rd(t)));
+__device__ __forceinline__ void stack_push(Trav& T, uint2* lds, uint2* ovf, uint32_t ref, float t_rd, Counters& cnt) {
+  uint2 e = make_uint2(ref, __float_as_uint(t_rd));
   if (T.sp < RT_LDS_STACK) lds[T.sp * 64] = e;
   else if (T.sp < RT_FAST_STACK_MAX) ovf[T.sp - RT_LDS_STACK] = e;
   else {
@@ -208,38 +223,51 @@ __device__ __forceinline__ void count_step(Counters& cnt) {  // statistics build
 }
 
 // Runs the lane's traversal to completion (lanes whose T.cur is RT_FREF_NONE have nothing to do).
-template <bool STATS>
-__device__ __forceinline__ void trav_run(const DevScene& s, Trav& T, uint2* lds, uint2* ovf, Counters& cnt) {
+// min_active > 0 (the streamed kernels, rt_stream.h): the loop is left, with the unfinished lanes' state intact, as soon as
+// fewer than min_active lanes of the wavefront are still traversing, so that the idle ones can fetch their next ray.
+template <bool STATS, int MS = MS_ALL>
+__device__ __forceinline__ void trav_run(const DevScene& s, Trav& T, uint2* lds, uint2* ovf, Counters& cnt, uint32_t min_active = 0) {
   while (T.cur != RT_FREF_NONE) {
+    if (min_active && (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(true)) < min_active) break;
     // ---- inner nodes: descend until this lane holds a leaf (or runs out of work) ----
     while ((T.cur >> RT_FREF_KIND_SHIFT) == RT_FREF_INNER) {
       if (STATS) count_step(cnt);
       const DevNode* node = s.nodes + (T.cur & RT_FREF_INDEX_MASK);
-      double bb0[6], bb1[6];
-      for (int k = 0; k < 6; k++) bb0[k] = node->bb[0][k];
-      for (int k = 0; k < 6; k++) bb1[k] = node->bb[1][k];
-      uint32_t r0 = node->ref[0], r1 = node->ref[1];
-      double t0, t1, x0, x1;
-      bool h0 = box_times(bb0, T.o, T.dinv, t0, x0);
-      bool h1 = box_times(bb1, T.o, T.dinv, t1, x1);
-      if (STATS) cnt.node_visits += 1u + (r1 != RT_FREF_NONE ? 1u : 0u);
       // a box can hold an accepted intersection only if it is entered no later than the limit (plus the window in
-      // which a runner-up must still be seen, see near_limit) ...
-      double lim = near_limit(T.limit);
-      h0 = h0 && !(t0 > lim) && r0 != RT_FREF_NONE;
-      h1 = h1 && !(t1 > lim) && r1 != RT_FREF_NONE;
-      if (T.mode != M_CONTAINERS) {  // ... and, for t >= 0 intersections, is not entirely behind the origin
-        h0 = h0 && !(x0 < 0.);
-        h1 = h1 && !(x1 < 0.);
+      // which a runner-up must still be seen, see near_limit) and, for t >= 0 intersections, is not entirely behind
+      // the origin.  key = entry time rounded down to f32 (what the stack keeps), +inf for a child not to be visited.
+      const double lim = near_limit(T.limit);
+      const bool all_t = in_mode<MS>(T, M_CONTAINERS);
+      float key[RT_NODE_WIDTH];
+      uint32_t ref[RT_NODE_WIDTH];
+      for (int c = 0; c < RT_NODE_WIDTH; c++) {
+        double bb[6];
+        for (int k = 0; k < 6; k++) bb[k] = (double)node->bb[c][k];
+        ref[c] = node->ref[c];
+        double t, x;
+        bool h = box_times(bb, T.o, T.dinv, t, x) && !(t > lim) && ref[c] != RT_FREF_NONE && (all_t || !(x < 0.));
+        if (STATS && ref[c] != RT_FREF_NONE) cnt.node_visits++;
+        key[c] = h ? __double2float_rd(t) : INFINITY;
       }
-      if (h0 && h1) {
-        bool swap = t1 < t0;  // near child first
-        stack_push(T, lds, ovf, swap ? r0 : r1, swap ? t0 : t1, cnt);
-        T.cur = swap ? r1 : r0;
-      } else if (h0) {
-        T.cur = r0;
-      } else if (h1) {
-        T.cur = r1;
+      // nearest child first: sort the four (key, ref) pairs ascending (5 compare-exchanges)
+#define RT_CSWAP(a, b)                                   \
+  {                                                      \
+    bool sw = key[b] < key[a];                           \
+    float ka = sw ? key[b] : key[a], kb = sw ? key[a] : key[b]; \
+    uint32_t ra = sw ? ref[b] : ref[a], rb = sw ? ref[a] : ref[b]; \
+    key[a] = ka; key[b] = kb; ref[a] = ra; ref[b] = rb;  \
+  }
+      RT_CSWAP(0, 1)
+      RT_CSWAP(2, 3)
+      RT_CSWAP(0, 2)
+      RT_CSWAP(1, 3)
+      RT_CSWAP(1, 2)
+#undef RT_CSWAP
+      if (key[0] < INFINITY) {
+        if (key[3] < INFINITY) stack_push(T, lds, ovf, ref[3], key[3], cnt);  // farthest deepest
+        if (key[2] < INFINITY) stack_push(T, lds, ovf, ref[2], key[2], cnt);
+        if (key[1] < INFINITY) stack_push(T, lds, ovf, ref[1], key[1], cnt);
+        T.cur = ref[0];
       } else {
         T.cur = stack_pop(T, lds, ovf);
       }
@@ -256,8 +284,8 @@ __device__ __forceinline__ void trav_run(const DevScene& s, Trav& T, uint2* lds,
         if (STATS) cnt.tri_tests++;
         if (triangle_roots(tri, T.o, T.d, &t, u, v)) {
           uint32_t prim = (uint32_t)__double_as_longlong(tri[9]);
-          uint32_t material = T.mode == M_SHADOW ? s.prim_info[prim].y : 0u;
-          add_roots<STATS>(s, T, prim, material, 1, &t, u, v);
+          uint32_t material = in_mode<MS>(T, M_SHADOW) ? s.prim_info[prim].y : 0u;
+          add_roots<STATS, MS>(s, T, prim, material, 1, &t, u, v);
         }
       }
     } else {  // RT_FREF_PRIMS
@@ -268,18 +296,31 @@ __device__ __forceinline__ void trav_run(const DevScene& s, Trav& T, uint2* lds,
           uint4 info = s.prim_info[idx];
           double ts[4], u, v;
           int n = prim_roots<STATS>(s, info, T.o, T.d, T.dinv, ts, u, v, cnt);
-          if (n) add_roots<STATS>(s, T, idx, info.y, n, ts, u, v);
+          if (n) add_roots<STATS, MS>(s, T, idx, info.y, n, ts, u, v);
         } else {
-          add_csg<STATS>(s, T, idx, cnt);
+          add_csg<STATS, MS>(s, T, idx, cnt);
         }
       }
     }
-    if (T.mode == M_SHADOW && T.a >= 1.) {  // min(intensity, 1) is already 1 (intersection.rs:124-126)
+    if (in_mode<MS>(T, M_SHADOW) && T.a >= 1.) {  // min(intensity, 1) is already 1 (intersection.rs:124-126)
       T.cur = RT_FREF_NONE;
       T.sp = 0;
     } else {
       T.cur = stack_pop(T, lds, ovf);
     }
+  }
+}
+
+// get_refractive (intersection.rs:258-302) from the result of the container walk for the hit primitive `hprim`.
+__device__ __forceinline__ void refractive_indices(const DevScene& s, const Trav& T, uint32_t hprim, double& n1, double& n2) {
+  n1 = 1.0;  // AIR_REFRACTIVE_INDEX (material.rs:7)
+  n2 = 1.0;
+  if (T.p != RT_NONE) n1 = s.material[(size_t)s.prim_info[T.p].y * RT_MAT_STRIDE + RT_MAT_REFRACTIVE_INDEX];
+  if (T.flag) {  // the hit object leaves the container list
+    uint32_t last = (T.p == hprim) ? T.q : T.p;
+    if (last != RT_NONE) n2 = s.material[(size_t)s.prim_info[last].y * RT_MAT_STRIDE + RT_MAT_REFRACTIVE_INDEX];
+  } else {  // the hit object becomes the innermost container
+    n2 = s.material[(size_t)s.prim_info[hprim].y * RT_MAT_STRIDE + RT_MAT_REFRACTIVE_INDEX];
   }
 }
 
@@ -435,15 +476,7 @@ __device__ __forceinline__ void run_machine(const DevScene& s, const DevOptions&
         ht = F.t;
         hu = F.u;
         hv = F.v;
-        n1 = 1.0;
-        n2 = 1.0;
-        if (T.p != RT_NONE) n1 = s.material[(size_t)s.prim_info[T.p].y * RT_MAT_STRIDE + RT_MAT_REFRACTIVE_INDEX];
-        if (T.flag) {  // the hit object leaves the container list
-          uint32_t last = (T.p == hprim) ? T.q : T.p;
-          if (last != RT_NONE) n2 = s.material[(size_t)s.prim_info[last].y * RT_MAT_STRIDE + RT_MAT_REFRACTIVE_INDEX];
-        } else {  // the hit object becomes the innermost container
-          n2 = s.material[(size_t)s.prim_info[hprim].y * RT_MAT_STRIDE + RT_MAT_REFRACTIVE_INDEX];
-        }
+        refractive_indices(s, T, hprim, n1, n2);
         pc = PC_HIT_READY;
       }
       if (pc == PC_HIT_READY) {  // IntersecComputations::new (intersection.rs:217-256)

@@ -1,0 +1,674 @@
+// rt_stream.h — the production render core: Renderer::color_at_pixel (src/render/renderer.rs:50-66) as a STREAM of
+// rays through small gfx950 kernels instead of one kernel that holds a pixel's whole recursion.
+//
+// Why: BVH traversal is bound by dependent-load latency, so it wants many resident wavefronts and every lane busy.  A
+// kernel that also carries the shading state machine needs ~240 VGPRs (2 waves per SIMD) and idles the lanes whose ray
+// has finished.  Here the traversal kernels hold nothing but the ray and its collector (4+ waves per SIMD), are
+// persistent, and a lane whose ray is finished takes the next ray from the queue at once.
+//
+// One batch of samples (a run of 8x8 tiles x all supersamples) flows through, level by level of the
+// reflect/refract recursion (integrator.rs:154-197):
+//
+//   level l = 0..max_depth:
+//     trace_closest   closest hit of every ray of the level (level 0: camera rays, generated in the kernel; deeper: the
+//                     queue written by the level above), then — same lane, same ray — the container walk when the hit
+//                     is transparent (intersection.rs:258-302).  Rays whose hit has a runner-up within the tie window
+//                     (coincident surfaces, see rt_fast.h) go to the retrace list instead.
+//     retrace         those few rays, settled in the reference's own visiting order (rt_reforder.h).
+//     shade           IntersecComputations::new for every hit (intersection.rs:217-256): one NODE record per hit
+//                     (over point, eye, normal, n1, n2), plus the reflected / refracted rays of level l+1.
+//   trace_shadow      one shadow ray per (node, light) for all nodes of all levels (integrator.rs:136-152).
+//   level l = max_depth..0:
+//     combine         shade_hit_at_depth's fold over the lights (integrator.rs:199-228) for every node of the level, in
+//                     the reference's operation order; the colour goes to the parent node's reflected / refracted slot,
+//                     or to the sample when l = 0.
+//   resolve           per pixel: the samples summed left to right, divided by n^2 (renderer.rs:57-65).
+//
+// Every arithmetic step is the same device function the single-kernel path (rt_fast.h) uses, applied to the same
+// operands in the same order, so the two are bit-identical; only WHEN a step runs differs.  Queue and node capacities
+// are bounded: a sample whose ray tree does not fit is flagged and re-rendered by the single-kernel state machine
+// (fallback_kernel), so capacity affects speed, never pixels.
+#pragma once
+#include "rt_fast.h"
+
+namespace stream {
+
+#define RT_RAY_STRIDE 8  // doubles per queued ray: origin, direction, (parent, root) as two u32, one spare
+#define RT_HIT_STRIDE 6  // doubles per hit record: primitive (u64 bits), t, u, v, n1, n2
+#define RT_LEVELS (RT_MAX_DEPTH + 1)
+
+// Node tables are struct-of-arrays: field f of node i at [f * cap_nodes + i], so that a wavefront working on consecutive
+// nodes reads and writes whole cache lines.
+enum { NF_OVER = 0, NF_EYE = 3, NF_NORMAL = 6, NF_N1 = 9, NF_N2 = 10, NF_REFL = 11, NF_REFR = 14, NF_COUNT = 17 };
+enum { NU_PRIM = 0, NU_PARENT = 1, NU_ROOT = 2, NU_COUNT = 3 };
+#define RT_NODE_REFLECTED 0x80000000u  // NU_PRIM: a reflected ray was traced for this hit (integrator.rs:154-168)
+#define RT_NODE_REFRACTED 0x40000000u  // NU_PRIM: a refracted ray was traced (integrator.rs:170-197)
+#define RT_NODE_PRIM_MASK 0x3FFFFFFFu
+#define RT_PARENT_REFRACT 0x80000000u  // NU_PARENT / ray link: the colour is the parent's REFRACTED one
+
+struct Ctrl {  // device-resident control block of one batch; zeroed when the batch starts
+  uint32_t n_rays[RT_LEVELS + 1];  // rays queued for each level (level 0: unused, its rays are the batch's samples)
+  unsigned long long fetch[RT_LEVELS][8];  // trace_closest: next ray of the level in each XCD's share (xcd_take)
+  uint32_t n_retrace[RT_LEVELS];
+  uint32_t level_end[RT_LEVELS];   // nodes [level_end[l-1], level_end[l]) belong to level l
+  uint32_t n_nodes;                // nodes allocated (may run past cap_nodes; clamped in level_end)
+  uint32_t n_flagged;              // samples handed to the fallback
+  unsigned long long shadow_fetch[8];
+};
+
+struct Ws {  // workspace of one batch (device pointers; owned by rt_scene)
+  Ctrl* ctrl;
+  double* rays[2];       // [cap_rays][RT_RAY_STRIDE]; level l reads rays[l & 1], writes rays[(l + 1) & 1]
+  double* hits;          // [max(n_samples, cap_rays)][RT_HIT_STRIDE] hit records of the level being processed
+  uint32_t* retrace;     // [max(n_samples, cap_rays)]
+  double* node_f;        // [NF_COUNT][cap_nodes]
+  uint32_t* node_u;      // [NU_COUNT][cap_nodes]
+  double* shadow;        // [n_lights][cap_nodes] accumulated shadow intensity (IntersectionCollector, intersection.rs:78-87)
+  double* sample_rgb;    // [n_samples][3]
+  uint8_t* sample_flag;  // [n_samples] 1: re-render this sample in the fallback kernel
+  uint32_t cap_rays, cap_nodes;
+};
+
+struct Batch {
+  uint32_t part, n_parts, tiles_x, n_owned;  // the tile partition, as rt_render_tiles_device defines it
+  uint32_t tile0, n_tiles;                   // this batch: positions [tile0, tile0 + n_tiles) of the part's tile order
+  uint32_t n2;                               // samples per pixel
+  uint32_t n_samples;                        // n_tiles * 64 * n2 (camera batch) or the number of given rays
+  uint32_t packed;
+  const double* given_o;                     // rt_trace_rays: level 0 is these rays ([n_samples][3] each) instead of the camera's
+  const double* given_d;
+};
+
+// ---------------------------------------------------------------------------------------------
+// wavefront helpers
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t rank_in(unsigned long long m) {  // number of set bits of m below this lane
+  return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+}
+
+// The lanes with `want` each get a distinct index from *counter (one atomic per wavefront); consecutive lanes get
+// consecutive indices.
+__device__ __forceinline__ uint32_t wave_take(uint32_t* counter, bool want) {
+  unsigned long long m = __builtin_amdgcn_ballot_w64(want);
+  uint32_t id = 0;
+  if (want) {
+    uint32_t r = rank_in(m), base = 0;
+    if (r == 0) base = atomicAdd(counter, (uint32_t)__builtin_popcountll(m));
+    base = __builtin_amdgcn_readfirstlane(base);
+    id = base + r;
+  }
+  return id;
+}
+__device__ __forceinline__ unsigned long long wave_take64(unsigned long long* counter, bool want) {
+  unsigned long long m = __builtin_amdgcn_ballot_w64(want);
+  unsigned long long id = 0;
+  if (want) {
+    uint32_t r = rank_in(m), lo = 0, hi = 0;
+    if (r == 0) {
+      unsigned long long base = atomicAdd(counter, (unsigned long long)__builtin_popcountll(m));
+      lo = (uint32_t)base;
+      hi = (uint32_t)(base >> 32);
+    }
+    lo = __builtin_amdgcn_readfirstlane(lo);
+    hi = __builtin_amdgcn_readfirstlane(hi);
+    id = (((unsigned long long)hi << 32) | lo) + r;
+  }
+  return id;
+}
+
+// XCD-aware work distribution for the persistent trace kernels.  Workgroup ids are dealt round-robin to the 8 XCDs, each
+// with its own 4 MB L2, so the items (rays in queue order = image order) are cut into chunks of RT_XCD_CHUNK and chunk c
+// belongs to XCD c % 8: the rays in flight on one XCD then cover a compact patch of the image and walk the same BVH
+// subtrees, which its L2 can hold.  Each XCD has its own counter over its share; a wavefront whose XCD's share is used
+// up takes from the next XCD's (`victim`, wave-uniform, only ever advances).  Returns ~0 when nothing is left.
+#ifndef RT_XCD_CHUNK
+#define RT_XCD_CHUNK 65536u
+#endif
+__device__ __forceinline__ unsigned long long xcd_take(unsigned long long* counters, unsigned long long n_items, uint32_t xcd,
+                                                       uint32_t& victim, bool want) {
+  unsigned long long id = ~0ull;
+  while (victim < 8u) {
+    bool w = want && id == ~0ull;
+    if (__builtin_amdgcn_ballot_w64(w) == 0ull) break;
+    uint32_t xx = (xcd + victim) & 7u;
+    unsigned long long q = wave_take64(&counters[xx], w);
+    bool failed = false;
+    if (w) {
+      unsigned long long g = ((q / RT_XCD_CHUNK) * 8u + xx) * RT_XCD_CHUNK + q % RT_XCD_CHUNK;
+      if (g < n_items) id = g;
+      else failed = true;
+    }
+    if (__builtin_amdgcn_ballot_w64(failed) != 0ull) victim++;  // ids only grow: that share is used up
+  }
+  return id;
+}
+
+__device__ __forceinline__ uint64_t dbits(double d) { return (uint64_t)__double_as_longlong(d); }
+__device__ __forceinline__ double bitsd(uint64_t u) { return __longlong_as_double((long long)u); }
+
+// Pixel of lane-slot p of the tile at position kpos of this part's tile order (the order rt_render_tiles_device packs).
+__device__ __forceinline__ void tile_pixel(const Batch& b, uint32_t kpos, uint32_t p, uint32_t& px, uint32_t& py) {
+  uint32_t k = kpos;
+  if (b.tiles_x % b.n_parts == 0) {  // this part's tiles form a regular grid: walk it block by block (L2 locality)
+    uint32_t gx = b.tiles_x / b.n_parts;
+    k = blocked_order(k, gx, b.n_owned / gx);
+  }
+  uint32_t tile = k * b.n_parts + b.part;
+  px = (tile % b.tiles_x) * RT_TILE_DIM + (p & 7u);
+  py = (tile / b.tiles_x) * RT_TILE_DIM + (p >> 3);
+}
+// Position in the PACKED output of that tile (rt_render_tiles_device: the k-th owned tile in row-major tile order).
+__device__ __forceinline__ uint32_t tile_packed_index(const Batch& b, uint32_t kpos) {
+  if (b.tiles_x % b.n_parts == 0) {
+    uint32_t gx = b.tiles_x / b.n_parts;
+    return blocked_order(kpos, gx, b.n_owned / gx);
+  }
+  return kpos;
+}
+
+// Sample id -> camera ray.  id = ((tile of the batch * n2) + sample k) * 64 + pixel slot, so 64 consecutive ids are one
+// sample of one 8x8 tile.  Camera::ray_for_pixel (camera.rs:189-201) at the offsets of renderer.rs:57-64 (dx outer).
+__device__ __forceinline__ bool camera_sample(const rt_camera& cam, const DevOptions& opt, const Batch& b, uint32_t id, d3& o, d3& d) {
+  uint32_t p = id & 63u, r = id >> 6, tl = r / b.n2, k = r - tl * b.n2;
+  uint32_t px, py;
+  tile_pixel(b, b.tile0 + tl, p, px, py);
+  if (px >= cam.width || py >= cam.height) return false;  // ragged edge: no such pixel
+  uint32_t i = k / opt.n_offsets, j = k - i * opt.n_offsets;
+  double ox = opt.offsets[0], oy = opt.offsets[0];
+  for (uint32_t q = 1; q < 5; q++) {  // select, not index: the options live in scalar registers
+    if (i == q) ox = opt.offsets[q];
+    if (j == q) oy = opt.offsets[q];
+  }
+  camera_ray(cam, (double)px + ox, (double)py + oy, o, d);
+  return true;
+}
+
+// The level-0 ray of sample `id`: the camera's, or the id-th given ray (rt_trace_rays).
+template <bool CAMERA>
+__device__ __forceinline__ bool first_ray(const rt_camera& cam, const DevOptions& opt, const Batch& b, uint32_t id, d3& o, d3& d) {
+  if (CAMERA) return camera_sample(cam, opt, b, id, o, d);
+  const double* po = b.given_o + (size_t)id * 3;
+  const double* pd = b.given_d + (size_t)id * 3;
+  o = mk3(po[0], po[1], po[2]);
+  d = mk3(pd[0], pd[1], pd[2]);
+  return true;
+}
+
+__device__ __forceinline__ void load_ray(const double* __restrict__ q, uint32_t id, d3& o, d3& d, uint32_t& parent, uint32_t& root) {
+  const double* r = q + (size_t)id * RT_RAY_STRIDE;
+  o = mk3(r[0], r[1], r[2]);
+  d = mk3(r[3], r[4], r[5]);
+  uint64_t link = dbits(r[6]);
+  parent = (uint32_t)link;
+  root = (uint32_t)(link >> 32);
+}
+__device__ __forceinline__ void store_ray(double* __restrict__ q, uint32_t id, d3 o, d3 d, uint32_t parent, uint32_t root) {
+  double* r = q + (size_t)id * RT_RAY_STRIDE;
+  r[0] = o.x;
+  r[1] = o.y;
+  r[2] = o.z;
+  r[3] = d.x;
+  r[4] = d.y;
+  r[5] = d.z;
+  r[6] = bitsd((uint64_t)parent | ((uint64_t)root << 32));
+}
+
+__device__ __forceinline__ void store_hit(double* __restrict__ hits, uint32_t id, uint32_t prim, double t, double u, double v, double n1,
+                                          double n2) {
+  double* h = hits + (size_t)id * RT_HIT_STRIDE;
+  h[0] = bitsd(prim);
+  if (prim != RT_NONE) {
+    h[1] = t;
+    h[2] = u;
+    h[3] = v;
+    h[4] = n1;
+    h[5] = n2;
+  }
+}
+
+__device__ __forceinline__ void flag_sample(const Ws& w, uint32_t root) {
+  w.sample_flag[root] = 1;
+  atomicAdd(&w.ctrl->n_flagged, 1u);
+}
+
+// ---------------------------------------------------------------------------------------------
+// trace_closest: persistent wavefronts; Integrator::intersect (integrator.rs:55-58) for every ray of one level, plus
+// the container walk of transparent hits.  A lane whose ray is finished fetches the next one as soon as fewer than
+// RT_REFILL_BELOW lanes of its wavefront are still traversing.
+// ---------------------------------------------------------------------------------------------
+#ifndef RT_TRACE_WAVES
+#define RT_TRACE_WAVES 4  // waves per SIMD the trace kernels are compiled for (<= 128 VGPRs)
+#endif
+#ifdef RT_HOST_EMU  // debugging harness (tools/hostemu): a wavefront is one lane
+#define RT_REFILL_BELOW 1
+#endif
+#ifndef RT_REFILL_BELOW
+#define RT_REFILL_BELOW 16
+#endif
+
+template <bool CAMERA, bool STATS>
+__global__ __launch_bounds__(64, RT_TRACE_WAVES) void trace_closest_kernel(DevScene s, rt_camera cam, DevOptions opt, Ws w, Batch b,
+                                                                          uint32_t level, unsigned long long* stats,
+                                                                          uint32_t* overflow_flag) {
+  __shared__ uint2 lds_stack[RT_LDS_STACK * 64];
+  uint2* lds = lds_stack + (threadIdx.x & 63u);
+  uint2 ovf[RT_OVF_STACK];
+  Counters cnt = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  const uint32_t n_rays = level == 0 ? b.n_samples : w.ctrl->n_rays[level];
+  const double* __restrict__ queue = w.rays[level & 1];
+  fast::Trav T;
+  T.cur = RT_FREF_NONE;
+  T.sp = 0;
+  T.mode = fast::M_CLOSEST;
+  T.limit = 0.;
+  uint32_t my = RT_NONE;  // the ray this lane is working on
+  double ht = 0., hu = 0., hv = 0.;  // the hit, kept across the container walk
+  bool exhausted = false;
+  uint32_t victim = 0;
+  for (;;) {
+    // ---- idle lanes take the next rays of the level ----
+    bool want = my == RT_NONE && !exhausted;
+    if (__builtin_amdgcn_ballot_w64(want) != 0ull) {
+      unsigned long long got = xcd_take(w.ctrl->fetch[level], n_rays, blockIdx.x & 7u, victim, want);
+      if (want) {
+        if (got != ~0ull) {
+          uint32_t id = (uint32_t)got;
+          d3 o, d;
+          bool ok = true;
+          if (level == 0) {
+            ok = first_ray<CAMERA>(cam, opt, b, id, o, d);
+          } else {
+            uint32_t parent, root;
+            load_ray(queue, id, o, d, parent, root);
+          }
+          if (ok) {
+            if (STATS && level == 0) cnt.rays_primary++;
+            my = id;
+            fast::trav_start(T, o, d, fast::M_CLOSEST, INFINITY);
+          } else {
+            store_hit(w.hits, id, RT_NONE, 0., 0., 0., 0., 0.);
+          }
+        } else {
+          exhausted = true;
+        }
+      }
+    }
+    if (__builtin_amdgcn_ballot_w64(T.cur != RT_FREF_NONE) == 0ull) {
+      if (__builtin_amdgcn_ballot_w64(!exhausted) == 0ull) break;
+      continue;
+    }
+    // ---- traverse; once the queue is dry there is nothing to refill with, so run to completion ----
+    uint32_t min_active = __builtin_amdgcn_ballot_w64(exhausted) != 0ull ? 0u : (uint32_t)RT_REFILL_BELOW;
+    fast::trav_run<STATS, fast::MS_CLOSEST_CONTAINERS>(s, T, lds, ovf, cnt, min_active);
+    // ---- lanes whose traversal is complete ----
+    if (my != RT_NONE && T.cur == RT_FREF_NONE) {
+      if (T.mode == fast::M_CLOSEST) {
+        if (T.p == RT_NONE) {  // miss
+          store_hit(w.hits, my, RT_NONE, 0., 0., 0., 0., 0.);
+          my = RT_NONE;
+        } else if (T.t2 <= fast::near_limit(T.limit)) {  // coincident surfaces: settled by the retrace kernel
+          uint32_t k = atomicAdd(&w.ctrl->n_retrace[level], 1u);
+          w.retrace[k] = my;
+          my = RT_NONE;
+        } else {
+          uint32_t m = s.prim_info[T.p].y;
+          if (!approx_eq(s.material[(size_t)m * RT_MAT_STRIDE + RT_MAT_TRANSPARENCY], 0.)) {
+            // Intersection::compute_refractive (intersection.rs:184-190): the negative-t intersections of this ray
+            ht = T.limit;
+            hu = T.a;
+            hv = T.b;
+            uint32_t hprim = T.p;
+            d3 o = T.o, d = T.d;
+            fast::trav_start(T, o, d, fast::M_CONTAINERS, 0.);
+            T.h = hprim;
+          } else {
+            store_hit(w.hits, my, T.p, T.limit, T.a, T.b, 1.0, 1.0);
+            my = RT_NONE;
+          }
+        }
+      } else {  // the container walk is complete
+        double n1, n2;
+        fast::refractive_indices(s, T, T.h, n1, n2);
+        store_hit(w.hits, my, T.h, ht, hu, hv, n1, n2);
+        T.mode = fast::M_CLOSEST;
+        my = RT_NONE;
+      }
+    }
+  }
+  flush_counters<STATS>(cnt, stats, overflow_flag);
+}
+
+// The rays of the retrace list: closest hit in the reference's visiting order (ObjectGroup::intersect_iter,
+// group.rs:171-201), then the container walk, exactly as the single-kernel state machine settles them.
+template <bool CAMERA, bool STATS>
+__global__ __launch_bounds__(64, 2) void retrace_kernel(DevScene s, rt_camera cam, DevOptions opt, Ws w, Batch b, uint32_t level,
+                                                        unsigned long long* stats, uint32_t* overflow_flag) {
+  __shared__ uint2 lds_stack[RT_LDS_STACK * 64];
+  uint2* lds = lds_stack + (threadIdx.x & 63u);
+  uint2 ovf[RT_OVF_STACK];
+  Counters cnt = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  const uint32_t n = w.ctrl->n_retrace[level];
+  const double* __restrict__ queue = w.rays[level & 1];
+  for (uint32_t i = blockIdx.x * 64u + (threadIdx.x & 63u); i < n; i += gridDim.x * 64u) {
+    uint32_t id = w.retrace[i];
+    d3 o, d;
+    if (level == 0) {
+      first_ray<CAMERA>(cam, opt, b, id, o, d);
+    } else {
+      uint32_t parent, root;
+      load_ray(queue, id, o, d, parent, root);
+    }
+    reforder::Coll c;
+    reforder::coll_init_closest(c);
+    reforder::traverse<reforder::MODE_CLOSEST, STATS>(s, o, d, c, cnt);
+    if (STATS) cnt.retraced++;
+    double n1 = 1.0, n2 = 1.0;
+    if (c.hit_prim != RT_NONE) {
+      uint32_t m = s.prim_info[c.hit_prim].y;
+      if (!approx_eq(s.material[(size_t)m * RT_MAT_STRIDE + RT_MAT_TRANSPARENCY], 0.)) {
+        fast::Trav T;
+        T.sp = 0;
+        fast::trav_start(T, o, d, fast::M_CONTAINERS, 0.);
+        T.h = c.hit_prim;
+        fast::trav_run<STATS, fast::MS_ALL>(s, T, lds, ovf, cnt);
+        fast::refractive_indices(s, T, c.hit_prim, n1, n2);
+      }
+    }
+    store_hit(w.hits, id, c.hit_prim, c.limit, c.hu, c.hv, n1, n2);
+  }
+  flush_counters<STATS>(cnt, stats, overflow_flag);
+}
+
+// ---------------------------------------------------------------------------------------------
+// shade: IntersecComputations::new (intersection.rs:217-256) for every hit of the level -> node records, and the
+// reflected / refracted rays of the next level (integrator.rs:154-197).
+// ---------------------------------------------------------------------------------------------
+template <bool CAMERA, bool STATS>
+__global__ __launch_bounds__(256) void shade_kernel(DevScene s, rt_camera cam, DevOptions opt, Ws w, Batch b, uint32_t level,
+                                                    unsigned long long* stats, uint32_t* overflow_flag) {
+  Counters cnt = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  const uint32_t n_rays = level == 0 ? b.n_samples : w.ctrl->n_rays[level];
+  const double* __restrict__ queue = w.rays[level & 1];
+  double* __restrict__ next = w.rays[(level + 1) & 1];
+  const size_t cap = w.cap_nodes;
+  const uint32_t lane = threadIdx.x & 63u;
+  for (uint32_t wbase = blockIdx.x * blockDim.x + (threadIdx.x - lane); wbase < n_rays; wbase += gridDim.x * blockDim.x) {
+    uint32_t id = wbase + lane;
+    bool valid = id < n_rays;
+    uint32_t prim = RT_NONE;
+    if (valid) prim = (uint32_t)dbits(w.hits[(size_t)id * RT_HIT_STRIDE]);
+    bool hit = valid && prim != RT_NONE;
+    d3 o = mk3(0., 0., 0.), d = mk3(0., 0., 1.);
+    uint32_t parent = id, root = id;  // level 0: the sample
+    if (valid && level != 0) load_ray(queue, id, o, d, parent, root);
+    if (valid && !hit && level == 0) {  // miss: black (integrator.rs:62-65)
+      double* c = w.sample_rgb + (size_t)parent * 3;
+      c[0] = 0.;
+      c[1] = 0.;
+      c[2] = 0.;
+    }
+    uint32_t node = wave_take(&w.ctrl->n_nodes, hit);
+    if (hit && node >= w.cap_nodes) {  // no room for this hit: the whole sample goes to the fallback
+      flag_sample(w, root);
+      hit = false;
+    }
+    bool want_reflect = false, want_refract = false;
+    d3 child_o[2], child_d[2];
+    if (hit) {
+      if (level == 0) first_ray<CAMERA>(cam, opt, b, id, o, d);
+      const double* h = w.hits + (size_t)id * RT_HIT_STRIDE;
+      double t = h[1], u = h[2], v = h[3], n1 = h[4], n2 = h[5];
+      uint4 info = s.prim_info[prim];
+      const double* mat = s.material + (size_t)info.y * RT_MAT_STRIDE;
+      HitGeom g = hit_geom(s, info, o, d, t, u, v);
+      if (STATS) {  // algorithmic bytes of shading this hit
+        cnt.hits++;
+        uint32_t bytes = 64u + 48u * s.n_lights;
+        bytes += info.x == RT_SHAPE_SMOOTH_TRIANGLE ? 72u : (info.x == RT_SHAPE_TRIANGLE ? 24u : (info.z != RT_NONE ? 96u : 0u));
+        if (s.pattern_kind[info.y] != RT_PATTERN_CONST) bytes += 144u;
+        cnt.hit_bytes += bytes;
+      }
+      // reflected_color_at_depth (integrator.rs:154-168)
+      if (level < opt.max_depth && !approx_eq(mat[RT_MAT_REFLECTIVITY], 0.)) {
+        want_reflect = true;
+        child_o[0] = g.over;
+        child_d[0] = g.reflect_v;
+      }
+      // refracted_color_at_depth (integrator.rs:170-197)
+      if (level < opt.max_depth && !approx_eq(mat[RT_MAT_TRANSPARENCY], 0.)) {
+        double ratio = n1 / n2;
+        double cos_i = dot3(g.eye, g.normal);
+        double sin2_t = (ratio * ratio) * (1. - cos_i * cos_i);
+        if (!(sin2_t > 1.)) {
+          double cos_t = sqrt(1. - sin2_t);
+          want_refract = true;
+          child_o[1] = g.under;
+          child_d[1] = sub3(scale3(g.normal, ratio * cos_i - cos_t), scale3(g.eye, ratio));
+        }
+      }
+      double* nf = w.node_f + node;
+      nf[(NF_OVER + 0) * cap] = g.over.x;
+      nf[(NF_OVER + 1) * cap] = g.over.y;
+      nf[(NF_OVER + 2) * cap] = g.over.z;
+      nf[(NF_EYE + 0) * cap] = g.eye.x;
+      nf[(NF_EYE + 1) * cap] = g.eye.y;
+      nf[(NF_EYE + 2) * cap] = g.eye.z;
+      nf[(NF_NORMAL + 0) * cap] = g.normal.x;
+      nf[(NF_NORMAL + 1) * cap] = g.normal.y;
+      nf[(NF_NORMAL + 2) * cap] = g.normal.z;
+      nf[NF_N1 * cap] = n1;
+      nf[NF_N2 * cap] = n2;
+      for (int k = 0; k < 6; k++) nf[(NF_REFL + k) * cap] = 0.;  // a child ray that misses returns black
+      uint32_t* nu = w.node_u + node;
+      nu[NU_PRIM * cap] = prim | (want_reflect ? RT_NODE_REFLECTED : 0u) | (want_refract ? RT_NODE_REFRACTED : 0u);
+      nu[NU_PARENT * cap] = parent;
+      nu[NU_ROOT * cap] = root;
+    }
+    // the rays of level + 1: the wavefront's reflected rays first, then its refracted rays
+    unsigned long long m1 = __builtin_amdgcn_ballot_w64(want_reflect), m2 = __builtin_amdgcn_ballot_w64(want_refract);
+    if (want_reflect || want_refract) {
+      uint32_t n1c = (uint32_t)__builtin_popcountll(m1), total = n1c + (uint32_t)__builtin_popcountll(m2);
+      uint32_t base = 0;
+      if (rank_in(m1 | m2) == 0) base = atomicAdd(&w.ctrl->n_rays[level + 1], total);
+      base = __builtin_amdgcn_readfirstlane(base);
+      if (want_reflect) {
+        uint32_t k = base + rank_in(m1);
+        if (k < w.cap_rays) {
+          store_ray(next, k, child_o[0], child_d[0], node, root);
+          if (STATS) cnt.rays_reflect++;
+        } else {
+          flag_sample(w, root);
+        }
+      }
+      if (want_refract) {
+        uint32_t k = base + n1c + rank_in(m2);
+        if (k < w.cap_rays) {
+          store_ray(next, k, child_o[1], child_d[1], node | RT_PARENT_REFRACT, root);
+          if (STATS) cnt.rays_refract++;
+        } else {
+          flag_sample(w, root);
+        }
+      }
+    }
+  }
+  flush_counters<STATS>(cnt, stats, overflow_flag);
+}
+
+// Closes a level: clamps the counters the shade kernel may have run past, and records where the level's nodes end.
+__global__ void close_level_kernel(Ws w, uint32_t level) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  Ctrl* c = w.ctrl;
+  if (c->n_nodes > w.cap_nodes) c->n_nodes = w.cap_nodes;
+  c->level_end[level] = c->n_nodes;
+  if (c->n_rays[level + 1] > w.cap_rays) c->n_rays[level + 1] = w.cap_rays;
+}
+
+// ---------------------------------------------------------------------------------------------
+// trace_shadow: Integrator::point_shadow_intensity_comps (integrator.rs:136-152) for every (node, light) pair.
+// Item id = light * n_nodes + node: a wavefront's lanes hold neighbouring nodes and the same light.
+// ---------------------------------------------------------------------------------------------
+template <bool STATS>
+__global__ __launch_bounds__(64, RT_TRACE_WAVES) void trace_shadow_kernel(DevScene s, Ws w, unsigned long long* stats,
+                                                                         uint32_t* overflow_flag) {
+  __shared__ uint2 lds_stack[RT_LDS_STACK * 64];
+  uint2* lds = lds_stack + (threadIdx.x & 63u);
+  uint2 ovf[RT_OVF_STACK];
+  Counters cnt = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  const uint32_t n_nodes = w.ctrl->n_nodes;
+  const unsigned long long n_items = (unsigned long long)n_nodes * s.n_lights;
+  const size_t cap = w.cap_nodes;
+  fast::Trav T;
+  T.cur = RT_FREF_NONE;
+  T.sp = 0;
+  T.mode = fast::M_SHADOW;
+  T.limit = 0.;
+  T.a = 0.;
+  unsigned long long my = ~0ull;
+  bool exhausted = false;
+  uint32_t victim = 0;
+  for (;;) {
+    bool want = my == ~0ull && !exhausted;
+    if (__builtin_amdgcn_ballot_w64(want) != 0ull) {
+      unsigned long long id = xcd_take(w.ctrl->shadow_fetch, n_items, blockIdx.x & 7u, victim, want);
+      if (want) {
+        if (id != ~0ull) {
+          uint32_t l = (uint32_t)(id / n_nodes), node = (uint32_t)(id - (unsigned long long)l * n_nodes);
+          const double* nf = w.node_f + node;
+          d3 over = mk3(nf[(NF_OVER + 0) * cap], nf[(NF_OVER + 1) * cap], nf[(NF_OVER + 2) * cap]);
+          const double* lp = s.light_pos + (size_t)l * 3;
+          d3 vv = sub3(mk3(lp[0], lp[1], lp[2]), over);  // get_point_shadow_dist_ray (integrator.rs:110-123)
+          double dist = mag3(vv);
+          d3 sdir = normalize3(vv);
+          if (STATS) cnt.rays_shadow++;
+          my = id;
+          fast::trav_start(T, over, sdir, fast::M_SHADOW, dist);
+        } else {
+          exhausted = true;
+        }
+      }
+    }
+    if (__builtin_amdgcn_ballot_w64(T.cur != RT_FREF_NONE) == 0ull) {
+      if (__builtin_amdgcn_ballot_w64(!exhausted) == 0ull) break;
+      continue;
+    }
+    uint32_t min_active = __builtin_amdgcn_ballot_w64(exhausted) != 0ull ? 0u : (uint32_t)RT_REFILL_BELOW;
+    fast::trav_run<STATS, fast::MS_SHADOW>(s, T, lds, ovf, cnt, min_active);
+    if (my != ~0ull && T.cur == RT_FREF_NONE) {
+      uint32_t l = (uint32_t)(my / n_nodes), node = (uint32_t)(my - (unsigned long long)l * n_nodes);
+      w.shadow[(size_t)l * cap + node] = T.a;
+      my = ~0ull;
+    }
+  }
+  flush_counters<STATS>(cnt, stats, overflow_flag);
+}
+
+// ---------------------------------------------------------------------------------------------
+// combine: Integrator::shade_hit_at_depth (integrator.rs:199-228) for every node of one level, deepest level first.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void combine_kernel(DevScene s, DevOptions opt, Ws w, uint32_t level) {
+  const uint32_t begin = level == 0 ? 0u : w.ctrl->level_end[level - 1], end = w.ctrl->level_end[level];
+  const size_t cap = w.cap_nodes;
+  for (uint32_t node = begin + blockIdx.x * blockDim.x + threadIdx.x; node < end; node += gridDim.x * blockDim.x) {
+    const double* nf = w.node_f + node;
+    const uint32_t* nu = w.node_u + node;
+    uint32_t pf = nu[NU_PRIM * cap], parent = nu[NU_PARENT * cap];
+    uint4 info = s.prim_info[pf & RT_NODE_PRIM_MASK];
+    const double* mat = s.material + (size_t)info.y * RT_MAT_STRIDE;
+    d3 over = mk3(nf[(NF_OVER + 0) * cap], nf[(NF_OVER + 1) * cap], nf[(NF_OVER + 2) * cap]);
+    d3 eye = mk3(nf[(NF_EYE + 0) * cap], nf[(NF_EYE + 1) * cap], nf[(NF_EYE + 2) * cap]);
+    d3 normal = mk3(nf[(NF_NORMAL + 0) * cap], nf[(NF_NORMAL + 1) * cap], nf[(NF_NORMAL + 2) * cap]);
+    double kr = mat[RT_MAT_REFLECTIVITY], kt = mat[RT_MAT_TRANSPARENCY];
+    d3 reflected = mk3(0., 0., 0.), refracted = mk3(0., 0., 0.);
+    if (pf & RT_NODE_REFLECTED) {  // color * reflectivity (integrator.rs:167)
+      reflected = mk3(nf[(NF_REFL + 0) * cap] * kr, nf[(NF_REFL + 1) * cap] * kr, nf[(NF_REFL + 2) * cap] * kr);
+    }
+    if (pf & RT_NODE_REFRACTED) {  // color * transparency (integrator.rs:196)
+      refracted = mk3(nf[(NF_REFR + 0) * cap] * kt, nf[(NF_REFR + 1) * cap] * kt, nf[(NF_REFR + 2) * cap] * kt);
+    }
+    bool use_schlick = kr > 0. && kt > 0. && !approx_eq(kr, 0.) && !approx_eq(kt, 0.);
+    d3 rr;
+    if (use_schlick) {
+      double reflectance = schlick(eye, normal, nf[NF_N1 * cap], nf[NF_N2 * cap]);
+      double k2 = 1. - reflectance;
+      rr = mk3(reflected.x * reflectance + refracted.x * k2, reflected.y * reflectance + refracted.y * k2,
+               reflected.z * reflectance + refracted.z * k2);
+    } else {
+      rr = add3(reflected, refracted);
+    }
+    d3 acc = mk3(0., 0., 0.);
+    for (uint32_t l = 0; l < s.n_lights; l++) {
+      double shadow = fmin(w.shadow[(size_t)l * cap + node], 1.);  // IntersectionCollector::shadow_intensity (intersection.rs:124-126)
+      if (!opt.shadow_intensity) shadow = approx_eq(shadow, 0.) ? 0. : 1.;
+      d3 surface = lighting(s, l, info, mat, over, eye, normal, shadow);
+      acc = add3(add3(acc, surface), rr);  // acc + surface + reflected_refracted
+    }
+    double* dst;
+    if (level == 0) dst = w.sample_rgb + (size_t)parent * 3;
+    else dst = w.node_f + ((parent & RT_PARENT_REFRACT) ? NF_REFR : NF_REFL) * cap + (parent & ~RT_PARENT_REFRACT);
+    size_t stride = level == 0 ? 1 : cap;
+    dst[0] = acc.x;
+    dst[stride] = acc.y;
+    dst[2 * stride] = acc.z;
+  }
+}
+
+// Samples whose ray tree did not fit the batch's queues: rendered by the single-kernel state machine (rt_fast.h).
+template <bool CAMERA>
+__global__ __launch_bounds__(64, 2) void fallback_kernel(DevScene s, rt_camera cam, DevOptions opt, Ws w, Batch b,
+                                                         unsigned long long* stats, uint32_t* overflow_flag) {
+  __shared__ uint2 lds_stack[RT_LDS_STACK * 64];
+  if (w.ctrl->n_flagged == 0) return;
+  if (stats && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&stats[RT_COUNTER_FALLBACK], (unsigned long long)w.ctrl->n_flagged);
+  Counters cnt = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  const uint32_t lane = threadIdx.x & 63u;
+  for (uint32_t wbase = blockIdx.x * 64u; wbase < b.n_samples; wbase += gridDim.x * 64u) {
+    uint32_t id = wbase + lane;
+    bool work = id < b.n_samples && w.sample_flag[id] != 0;
+    if (__builtin_amdgcn_ballot_w64(work) == 0ull) continue;
+    fast::OneRay rays;
+    rays.o = mk3(0., 0., 0.);
+    rays.d = mk3(0., 0., 1.);
+    rays.pending = true;
+    rays.color = mk3(0., 0., 0.);
+    if (work) work = first_ray<CAMERA>(cam, opt, b, id, rays.o, rays.d);
+    fast::run_machine<false>(s, opt, rays, work, lds_stack + lane, cnt);
+    if (work) {
+      double* c = w.sample_rgb + (size_t)id * 3;
+      c[0] = rays.color.x;
+      c[1] = rays.color.y;
+      c[2] = rays.color.z;
+    }
+  }
+  if (cnt.overflow) atomicOr(overflow_flag, 1u);
+}
+
+// resolve: Renderer::color_at_pixel's sum over the samples, left to right from black, then / n^2 (renderer.rs:57-65).
+__global__ __launch_bounds__(256) void resolve_kernel(rt_camera cam, Ws w, Batch b, double* __restrict__ out) {
+  const uint32_t n_pixels = b.n_tiles * 64u;
+  const double nn = (double)b.n2;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_pixels; i += gridDim.x * blockDim.x) {
+    uint32_t tl = i >> 6, p = i & 63u;
+    uint32_t px, py;
+    tile_pixel(b, b.tile0 + tl, p, px, py);
+    bool inside = px < cam.width && py < cam.height;
+    d3 color = mk3(0., 0., 0.);
+    if (inside) {
+      const double* src = w.sample_rgb + ((size_t)tl * b.n2 * 64u + p) * 3;
+      for (uint32_t k = 0; k < b.n2; k++, src += 64 * 3) color = add3(color, mk3(src[0], src[1], src[2]));
+    }
+    color = mk3(color.x / nn, color.y / nn, color.z / nn);  // renderer.rs:65
+    if (b.packed) {
+      double* dst = out + ((size_t)tile_packed_index(b, b.tile0 + tl) * 64 + p) * 3;
+      dst[0] = color.x;
+      dst[1] = color.y;
+      dst[2] = color.z;
+    } else if (inside) {
+      double* dst = out + ((size_t)py * cam.width + px) * 3;
+      dst[0] = color.x;
+      dst[1] = color.y;
+      dst[2] = color.z;
+    }
+  }
+}
+
+}  // namespace stream

@@ -17,7 +17,8 @@
 // ---------------------------------------------------------------------------------------------
 // kernels
 // ---------------------------------------------------------------------------------------------
-#define RT_N_COUNTERS 15
+#define RT_N_COUNTERS 16
+#define RT_COUNTER_FALLBACK 15  // streamed pipeline: flag events of samples handed to the fallback kernel
 #ifndef RT_WAVES_PER_EU
 #define RT_WAVES_PER_EU 2  // waves per SIMD the register allocator must leave room for (256 VGPRs: no spills; measured best)
 #endif
@@ -26,10 +27,10 @@ template <bool STATS>
 __device__ __forceinline__ void flush_counters(const Counters& c, unsigned long long* stats, uint32_t* overflow_flag) {
   if (c.overflow) atomicOr(overflow_flag, 1u);
   if (!STATS) return;
-  uint32_t v[RT_N_COUNTERS] = {c.rays_primary, c.rays_shadow, c.rays_reflect, c.rays_refract, c.node_visits, c.tri_tests,
+  uint32_t v[15] = {c.rays_primary, c.rays_shadow, c.rays_reflect, c.rays_refract, c.node_visits, c.tri_tests,
                                c.prim_tests,   c.hits,        c.hit_bytes,    c.overflow,     c.wave_steps,  c.lane_steps,
                                c.retraced,     c.cyc_trav,    c.cyc_adv};
-  for (int k = 0; k < RT_N_COUNTERS; k++) {
+  for (int k = 0; k < 15; k++) {
     unsigned long long x = v[k];
     for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
     if ((threadIdx.x & 63) == 0 && x) atomicAdd(&stats[k], x);
@@ -72,8 +73,11 @@ __device__ __forceinline__ uint32_t blocked_order(uint32_t j, uint32_t gx, uint3
   return (r * RT_BLOCK + cy) * gx + cx;
 }
 
-// Renderer::color_at_pixel (renderer.rs:50-66) for one 8x8 tile per wavefront.
-// REFORDER = false: the production core (rt_fast.h).  REFORDER = true: reference visiting order (rt_reforder.h).
+#include "rt_stream.h"  // the production pipeline (uses flush_counters and blocked_order above)
+
+// Renderer::color_at_pixel (renderer.rs:50-66) for one 8x8 tile per wavefront, the whole recursion in one kernel.
+// REFORDER = false: the single-kernel core (rt_fast.h; rt_options.pipeline = 1, and the fallback of the streamed
+// pipeline).  REFORDER = true: reference visiting order (rt_reforder.h).
 template <bool STATS, bool REFORDER>
 __global__ __launch_bounds__(64, REFORDER ? 2 : RT_WAVES_PER_EU) void render_tiles_kernel(DevScene s, rt_camera cam, DevOptions opt, uint32_t part,
                                                                             uint32_t n_parts, uint32_t tiles_x, uint32_t n_owned,
@@ -238,6 +242,16 @@ struct rt_scene {
   uint32_t* d_overflow = nullptr;
   size_t bytes = 0;
   uint32_t stack_need = 0;
+  uint32_t n_lights = 0;
+  int n_cus = 256;
+  // workspace of the streamed pipeline: allocated at the first render, kept for the scene's lifetime, grown on demand
+  mutable void* ws_base = nullptr;
+  mutable size_t ws_bytes = 0;
+  mutable uint32_t ws_samples = 0;  // batch capacity in samples
+  mutable stream::Ws ws{};
+  ~rt_scene() {
+    if (ws_base) (void)hipFree(ws_base);
+  }
 };
 
 namespace {
@@ -284,8 +298,15 @@ uint32_t stack_need(const rt_scene_desc* d, uint32_t node, std::vector<int64_t>&
 // ---------------------------------------------------------------------------------------------
 // Device layout of the fast path (rt_device.h): binary 128-B nodes, leaf runs, visit ranks.
 // ---------------------------------------------------------------------------------------------
+struct BinNode {  // the binary tree before the fold: exact f64 boxes of both children
+  double bb[2][6];
+  uint32_t ref[2];
+};
+
 struct FastLayout {
-  std::vector<DevNode> nodes;
+  std::vector<BinNode> bin;    // node 0 is a synthetic root whose child 0 is the scene's root group
+  std::vector<DevNode> nodes;  // the 4-wide nodes the device walks (fold_nodes)
+  uint32_t stack_need = 0;     // most entries the device traversal stack can hold at once
   std::vector<uint32_t> leaf_ref;
   std::vector<uint32_t> prim_rank;
   std::vector<uint32_t> prim_tri;  // triangle primitives: slot in the device triangle tables (leaf order), else RT_NONE
@@ -293,6 +314,19 @@ struct FastLayout {
   uint32_t depth = 0;
   std::string error;
 };
+
+// The reference's f64 box, rounded outward to the node's f32 fields (min down, max up): a superset of the box.
+void set_node_box(DevNode& n, int child, const double* bb) {
+  for (int k = 0; k < 6; k++) {
+    float f = (float)bb[k];
+    if (k < 3) {
+      if ((double)f > bb[k]) f = std::nextafterf(f, -INFINITY);
+    } else {
+      if ((double)f < bb[k]) f = std::nextafterf(f, INFINITY);
+    }
+    n.bb[child][k] = f;
+  }
+}
 
 struct FastItem {  // how a parent refers to one child: reference + the box tested before entering it
   uint32_t ref;
@@ -364,10 +398,9 @@ void make_leaves(const rt_scene_desc* d, FastLayout& L, const std::vector<uint32
 // Folds items into binary nodes; returns the reference to the (sub)tree holding all of them.  Synthetic inner
 // references are tested behind `bb` again (a box the ray is already known to hit).
 uint32_t fold_items(FastLayout& L, const std::vector<FastItem>& items, size_t from, const double* bb) {
-  uint32_t id = (uint32_t)L.nodes.size();
-  L.nodes.emplace_back();
-  std::memset(&L.nodes[id], 0, sizeof(DevNode));
-  DevNode n;
+  uint32_t id = (uint32_t)L.bin.size();
+  L.bin.emplace_back();
+  BinNode n;
   std::memset(&n, 0, sizeof(n));
   std::memcpy(n.bb[0], items[from].bb, sizeof(n.bb[0]));
   n.ref[0] = items[from].ref;
@@ -381,7 +414,7 @@ uint32_t fold_items(FastLayout& L, const std::vector<FastItem>& items, size_t fr
     std::memcpy(n.bb[1], bb, sizeof(n.bb[1]));
     n.ref[1] = fold_items(L, items, from + 1, bb);
   }
-  L.nodes[id] = n;
+  L.bin[id] = n;
   return RT_MAKE_FREF(RT_FREF_INNER, 0, id);
 }
 
@@ -415,19 +448,93 @@ uint32_t build_group(const rt_scene_desc* d, FastLayout& L, uint32_t g, uint32_t
   return fold_items(L, items, 0, bb);
 }
 
+// Folds the binary tree into RT_NODE_WIDTH-wide nodes: the slots of a wide node start as the two children of a binary
+// node; while a slot is free, the inner child with the largest box is replaced by ITS two children (its own box is then
+// never tested: the children's boxes are tested directly).  Also finds the deepest the traversal stack can get: a
+// visit of a node with k children pushes at most k - 1 of them.
+void fold_nodes(FastLayout& L) {
+  struct Slot {
+    double bb[6];
+    uint32_t ref;
+  };
+  auto inner = [](uint32_t r) { return r != RT_FREF_NONE && (r >> RT_FREF_KIND_SHIFT) == RT_FREF_INNER; };
+  auto area = [](const double* b) {
+    double dx = b[3] - b[0], dy = b[4] - b[1], dz = b[5] - b[2];
+    double a = dx * dy + dy * dz + dz * dx;
+    return a == a ? a : INFINITY;
+  };
+  L.nodes.clear();
+  L.nodes.emplace_back();
+  struct Todo {
+    uint32_t bin, wide, held;  // binary node to fold, its wide node, stack entries held while inside it
+  };
+  std::vector<Todo> todo{{0u, 0u, 0u}};
+  L.stack_need = 0;
+  while (!todo.empty()) {
+    Todo t = todo.back();
+    todo.pop_back();
+    std::vector<Slot> slots;
+    auto add_children = [&](uint32_t b) {
+      for (int c = 0; c < 2; c++) {
+        if (L.bin[b].ref[c] == RT_FREF_NONE) continue;
+        Slot sl;
+        std::memcpy(sl.bb, L.bin[b].bb[c], sizeof(sl.bb));
+        sl.ref = L.bin[b].ref[c];
+        slots.push_back(sl);
+      }
+    };
+    add_children(t.bin);
+    for (;;) {
+      int best = -1;
+      for (size_t i = 0; i < slots.size(); i++) {
+        if (!inner(slots[i].ref)) continue;
+        const BinNode& bn = L.bin[slots[i].ref & RT_FREF_INDEX_MASK];
+        size_t kids = (bn.ref[0] != RT_FREF_NONE) + (bn.ref[1] != RT_FREF_NONE);
+        if (slots.size() - 1 + kids > RT_NODE_WIDTH) continue;
+        if (best < 0 || area(slots[i].bb) > area(slots[best].bb)) best = (int)i;
+      }
+      if (best < 0) break;
+      uint32_t b = slots[best].ref & RT_FREF_INDEX_MASK;
+      slots.erase(slots.begin() + best);
+      add_children(b);
+    }
+    DevNode n;
+    std::memset(&n, 0, sizeof(n));
+    uint32_t held = t.held + (slots.empty() ? 0u : (uint32_t)slots.size() - 1u);
+    if (held > L.stack_need) L.stack_need = held;
+    for (int i = 0; i < RT_NODE_WIDTH; i++) {
+      if ((size_t)i >= slots.size()) {
+        n.ref[i] = RT_FREF_NONE;
+        continue;
+      }
+      set_node_box(n, i, slots[i].bb);
+      if (inner(slots[i].ref)) {
+        uint32_t wide = (uint32_t)L.nodes.size();
+        L.nodes.emplace_back();
+        n.ref[i] = RT_MAKE_FREF(RT_FREF_INNER, 0, wide);
+        todo.push_back({slots[i].ref & RT_FREF_INDEX_MASK, wide, held});
+      } else {
+        n.ref[i] = slots[i].ref;
+      }
+    }
+    L.nodes[t.wide] = n;
+  }
+}
+
 bool build_fast_layout(const rt_scene_desc* d, FastLayout& L) {
   assign_ranks(d, L.prim_rank);
   L.prim_tri.assign(d->n_prims, RT_NONE);
-  L.nodes.reserve((size_t)d->n_nodes + 2);
-  L.nodes.emplace_back();  // node 0: the synthetic root
+  L.bin.reserve((size_t)d->n_nodes + 2);
+  L.bin.emplace_back();  // node 0: the synthetic root
   uint32_t root = build_group(d, L, 0, 1);
   if (!L.error.empty()) return false;
-  DevNode n;
+  BinNode n;
   std::memset(&n, 0, sizeof(n));
   std::memcpy(n.bb[0], d->node_bbox, sizeof(n.bb[0]));
   n.ref[0] = root;
   n.ref[1] = RT_FREF_NONE;
-  L.nodes[0] = n;
+  L.bin[0] = n;
+  fold_nodes(L);
   // triangles outside triangle-only leaves (mixed leaves, CSG operands) still need a slot in the triangle tables
   for (uint32_t i = 0; i < d->n_prims; i++) {
     uint8_t sh = d->prim_shape[i];
@@ -505,6 +612,7 @@ int check_render_args(const rt_scene* scene, const rt_camera* cam, const rt_opti
   if (opt->n_offsets < 1 || opt->n_offsets > 5) return fail(RT_ERR_INVALID_ARGUMENT, "n_offsets must be 1..5");
   if (opt->max_depth > RT_MAX_DEPTH)
     return fail(RT_ERR_UNSUPPORTED, "max_depth exceeds the device limit RT_MAX_DEPTH (16)");
+  if (opt->pipeline > RT_PIPELINE_SINGLE_KERNEL) return fail(RT_ERR_INVALID_ARGUMENT, "unknown rt_options.pipeline");
   return RT_OK;
 }
 
@@ -512,6 +620,147 @@ uint32_t tiles_total(uint32_t w, uint32_t h, uint32_t* tiles_x) {
   uint32_t tx = (w + RT_TILE_DIM - 1) / RT_TILE_DIM, ty = (h + RT_TILE_DIM - 1) / RT_TILE_DIM;
   if (tiles_x) *tiles_x = tx;
   return tx * ty;
+}
+
+// ---------------------------------------------------------------------------------------------
+// The streamed pipeline (rt_stream.h): workspace and launch sequence
+// ---------------------------------------------------------------------------------------------
+size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+#define RT_STREAM_NODES_PER_SAMPLE 3u  // node records per sample of a batch; a sample that needs more goes to the fallback
+
+// Bytes of workspace per sample of a batch: two ray queues, hit records, retrace list, 3 nodes' worth of node tables and
+// shadow results, the sample's colour and flag.
+size_t ws_bytes_per_sample(uint32_t n_lights) {
+  return 2 * RT_RAY_STRIDE * 8 + RT_HIT_STRIDE * 8 + 4 +
+         RT_STREAM_NODES_PER_SAMPLE * (stream::NF_COUNT * 8 + stream::NU_COUNT * 4 + (size_t)n_lights * 8) + 24 + 1;
+}
+
+// Makes sure the scene's workspace holds batches of min(want, limit) samples.  limit: RT_STREAM_BATCH_SAMPLES (default
+// 32 Mi samples), and never more than a third of the device's free memory.
+int ensure_workspace(const rt_scene* sc, uint64_t want_samples, uint32_t* batch_samples) {
+  uint64_t limit = 32ull << 20;
+  if (const char* e = std::getenv("RT_STREAM_BATCH_SAMPLES")) {
+    unsigned long long v = std::strtoull(e, nullptr, 10);
+    if (v >= 64) limit = v;
+  }
+  if (limit > (1ull << 30)) limit = 1ull << 30;  // node ids carry two flag bits
+  uint64_t n = std::min<uint64_t>(want_samples, limit);
+  n = std::max<uint64_t>(align_up(n, 64), 64);
+  if (sc->ws_base && sc->ws_samples >= n) {
+    *batch_samples = (uint32_t)std::min<uint64_t>(sc->ws_samples, std::max<uint64_t>(align_up(want_samples, 64), 64));
+    return RT_OK;
+  }
+  size_t per = ws_bytes_per_sample(sc->n_lights);
+  size_t free_b = 0, total_b = 0;
+  if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b > 0) {
+    uint64_t fit = (free_b / 3 + sc->ws_bytes) / (per + 64);
+    if (fit < 4096) return fail(RT_ERR_DEVICE, "not enough free device memory for the render workspace");
+    if (n > fit) n = fit / 64 * 64;
+  }
+  if (sc->ws_base) {
+    (void)hipFree(sc->ws_base);
+    sc->ws_base = nullptr;
+    sc->ws_bytes = 0;
+    sc->ws_samples = 0;
+  }
+  const size_t A = 256;
+  uint32_t cap_rays = (uint32_t)n, cap_nodes = RT_STREAM_NODES_PER_SAMPLE * (uint32_t)n;
+  size_t off = 0, o_ctrl, o_rays0, o_rays1, o_hits, o_retrace, o_nf, o_nu, o_shadow, o_rgb, o_flag;
+  auto take = [&](size_t bytes) {
+    size_t at = off;
+    off = align_up(off + bytes, A);
+    return at;
+  };
+  o_ctrl = take(sizeof(stream::Ctrl));
+  o_rays0 = take((size_t)cap_rays * RT_RAY_STRIDE * 8);
+  o_rays1 = take((size_t)cap_rays * RT_RAY_STRIDE * 8);
+  o_hits = take((size_t)n * RT_HIT_STRIDE * 8);
+  o_retrace = take((size_t)n * 4);
+  o_nf = take((size_t)cap_nodes * stream::NF_COUNT * 8);
+  o_nu = take((size_t)cap_nodes * stream::NU_COUNT * 4);
+  o_shadow = take((size_t)cap_nodes * std::max<uint32_t>(sc->n_lights, 1u) * 8);
+  o_rgb = take((size_t)n * 24);
+  o_flag = take((size_t)n);
+  void* base = nullptr;
+  if (hipMalloc(&base, off) != hipSuccess)
+    return fail(RT_ERR_DEVICE, "hipMalloc of the render workspace (" + std::to_string(off >> 20) + " MiB) failed");
+  char* b = (char*)base;
+  sc->ws_base = base;
+  sc->ws_bytes = off;
+  sc->ws_samples = (uint32_t)n;
+  sc->ws.ctrl = (stream::Ctrl*)(b + o_ctrl);
+  sc->ws.rays[0] = (double*)(b + o_rays0);
+  sc->ws.rays[1] = (double*)(b + o_rays1);
+  sc->ws.hits = (double*)(b + o_hits);
+  sc->ws.retrace = (uint32_t*)(b + o_retrace);
+  sc->ws.node_f = (double*)(b + o_nf);
+  sc->ws.node_u = (uint32_t*)(b + o_nu);
+  sc->ws.shadow = (double*)(b + o_shadow);
+  sc->ws.sample_rgb = (double*)(b + o_rgb);
+  sc->ws.sample_flag = (uint8_t*)(b + o_flag);
+  sc->ws.cap_rays = cap_rays;
+  sc->ws.cap_nodes = cap_nodes;
+  *batch_samples = (uint32_t)std::min<uint64_t>(n, std::max<uint64_t>(align_up(want_samples, 64), 64));
+  return RT_OK;
+}
+
+// One batch through every level (see rt_stream.h).  CAMERA: level 0 is generated from the camera; otherwise it is the
+// batch's given rays (rt_trace_rays).
+template <bool CAMERA, bool STATS>
+int run_stream_batch(const rt_scene* sc, const rt_camera& cam, const DevOptions& dopt, const stream::Batch& b, hipStream_t st) {
+  const stream::Ws& w = sc->ws;
+  const uint32_t trace_grid = (uint32_t)sc->n_cus * 4u * RT_TRACE_WAVES;
+  const uint32_t wide_grid = (uint32_t)sc->n_cus * 8u;
+  uint32_t need = (b.n_samples + 255u) / 256u;
+  const uint32_t first_grid = std::max(1u, std::min(wide_grid, need));
+  HIP_TRY(hipMemsetAsync(w.ctrl, 0, sizeof(stream::Ctrl), st));
+  HIP_TRY(hipMemsetAsync(w.sample_flag, 0, b.n_samples, st));
+  for (uint32_t level = 0; level <= dopt.max_depth; level++) {
+    hipLaunchKernelGGL((stream::trace_closest_kernel<CAMERA, STATS>), dim3(trace_grid), dim3(64), 0, st, sc->dev, cam, dopt, w, b, level,
+                       sc->d_stats, sc->d_overflow);
+    hipLaunchKernelGGL((stream::retrace_kernel<CAMERA, STATS>), dim3((uint32_t)sc->n_cus), dim3(64), 0, st, sc->dev, cam, dopt, w, b, level,
+                       sc->d_stats, sc->d_overflow);
+    hipLaunchKernelGGL((stream::shade_kernel<CAMERA, STATS>), dim3(level == 0 ? first_grid : wide_grid), dim3(256), 0, st, sc->dev, cam,
+                       dopt, w, b, level, sc->d_stats, sc->d_overflow);
+    hipLaunchKernelGGL(stream::close_level_kernel, dim3(1), dim3(64), 0, st, w, level);
+  }
+  hipLaunchKernelGGL((stream::trace_shadow_kernel<STATS>), dim3(trace_grid), dim3(64), 0, st, sc->dev, w, sc->d_stats, sc->d_overflow);
+  for (uint32_t level = dopt.max_depth + 1; level-- > 0;)
+    hipLaunchKernelGGL(stream::combine_kernel, dim3(wide_grid), dim3(256), 0, st, sc->dev, dopt, w, level);
+  hipLaunchKernelGGL((stream::fallback_kernel<CAMERA>), dim3((uint32_t)sc->n_cus * 8u), dim3(64), 0, st, sc->dev, cam, dopt, w, b,
+                     STATS ? sc->d_stats : nullptr, sc->d_overflow);
+  HIP_TRY(hipGetLastError());
+  return RT_OK;
+}
+
+template <bool STATS>
+int launch_stream_render(const rt_scene* sc, const rt_camera* cam, const DevOptions& dopt, uint32_t part, uint32_t n_parts,
+                         uint32_t tiles_x, uint32_t n_owned, int packed, double* d_out, hipStream_t st) {
+  const uint32_t n2 = dopt.n_offsets * dopt.n_offsets, per_tile = 64u * n2;
+  uint32_t batch_samples = 0;
+  int rc = ensure_workspace(sc, (uint64_t)n_owned * per_tile, &batch_samples);
+  if (rc) return rc;
+  const uint32_t tiles_per_batch = std::max(1u, batch_samples / per_tile);
+  if (tiles_per_batch * per_tile > sc->ws_samples) return fail(RT_ERR_DEVICE, "render workspace smaller than one tile");
+  for (uint32_t tile0 = 0; tile0 < n_owned; tile0 += tiles_per_batch) {
+    stream::Batch b;
+    b.part = part;
+    b.n_parts = n_parts;
+    b.tiles_x = tiles_x;
+    b.n_owned = n_owned;
+    b.tile0 = tile0;
+    b.n_tiles = std::min(tiles_per_batch, n_owned - tile0);
+    b.n2 = n2;
+    b.n_samples = b.n_tiles * per_tile;
+    b.packed = (uint32_t)packed;
+    b.given_o = b.given_d = nullptr;
+    rc = run_stream_batch<true, STATS>(sc, *cam, dopt, b, st);
+    if (rc) return rc;
+    uint32_t grid = std::max(1u, std::min((uint32_t)sc->n_cus * 8u, (b.n_tiles * 64u + 255u) / 256u));
+    hipLaunchKernelGGL(stream::resolve_kernel, dim3(grid), dim3(256), 0, st, *cam, sc->ws, b, d_out);
+  }
+  HIP_TRY(hipGetLastError());
+  return RT_OK;
 }
 
 int launch_render(const rt_scene* scene, const rt_camera* cam, const rt_options* opt, uint32_t part, uint32_t n_parts, int packed,
@@ -540,9 +789,13 @@ int launch_render(const rt_scene* scene, const rt_camera* cam, const rt_options*
     if (opt->reference_order) {
       if (stats) RT_LAUNCH_TILES(true, true);
       else RT_LAUNCH_TILES(false, true);
-    } else {
+    } else if (opt->pipeline == RT_PIPELINE_SINGLE_KERNEL) {
       if (stats) RT_LAUNCH_TILES(true, false);
       else RT_LAUNCH_TILES(false, false);
+    } else {
+      rc = stats ? launch_stream_render<true>(scene, cam, dopt, part, n_parts, tiles_x, n_owned, packed, d_out, stream)
+                 : launch_stream_render<false>(scene, cam, dopt, part, n_parts, tiles_x, n_owned, packed, d_out, stream);
+      if (rc) return rc;
     }
 #undef RT_LAUNCH_TILES
     HIP_TRY(hipGetLastError());
@@ -574,6 +827,7 @@ int launch_render(const rt_scene* scene, const rt_camera* cam, const rt_options*
     stats->rays_retraced = h[12];
     stats->clocks_traversal = h[13] * 64;
     stats->clocks_machine = h[14] * 64;
+    stats->fallback_flags = h[15];
     stats->ms_kernel = ms;
     if (ovf) return fail(RT_ERR_OVERFLOW, "a per-ray bounded list (BVH stack or CSG hit list) overflowed on the device");
   }
@@ -627,22 +881,9 @@ int rt_scene_create(const rt_scene_desc* d, rt_scene** out) {
   }
   FastLayout L;
   if (!build_fast_layout(d, L)) return fail(RT_ERR_UNSUPPORTED, L.error);
-  {  // near-child-first traversal pushes at most one sibling per level: the stack never exceeds the node depth
-    uint32_t deepest = 0;
-    std::vector<std::pair<uint32_t, uint32_t>> st{{0u, 1u}};
-    while (!st.empty()) {
-      auto [node, depth] = st.back();
-      st.pop_back();
-      if (depth > deepest) deepest = depth;
-      for (int c = 0; c < 2; c++) {
-        uint32_t r = L.nodes[node].ref[c];
-        if (r != RT_FREF_NONE && (r >> RT_FREF_KIND_SHIFT) == RT_FREF_INNER) st.push_back({r & RT_FREF_INDEX_MASK, depth + 1});
-      }
-    }
-    if (deepest > RT_FAST_STACK_MAX)
-      return fail(RT_ERR_UNSUPPORTED, "the BVH is " + std::to_string(deepest) + " nodes deep; the device traversal stack holds " +
-                                          std::to_string(RT_FAST_STACK_MAX));
-  }
+  if (L.stack_need > RT_FAST_STACK_MAX)
+    return fail(RT_ERR_UNSUPPORTED, "the BVH needs a device traversal stack of " + std::to_string(L.stack_need) + " entries; it holds " +
+                                        std::to_string(RT_FAST_STACK_MAX));
   std::vector<uint4> prim_info(d->n_prims);
   for (uint32_t i = 0; i < d->n_prims; i++) {
     bool tri = d->prim_shape[i] == RT_SHAPE_TRIANGLE || d->prim_shape[i] == RT_SHAPE_SMOOTH_TRIANGLE;
@@ -715,6 +956,11 @@ int rt_scene_create(const rt_scene_desc* d, rt_scene** out) {
 #undef UPA
   sc->dev.n_lights = d->n_lights;
   sc->dev.n_prims = d->n_prims;
+  sc->n_lights = d->n_lights;
+  {
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, sc->device) == hipSuccess && cus > 0) sc->n_cus = cus;
+  }
   void* p = nullptr;
   if (hipMalloc(&p, RT_N_COUNTERS * sizeof(unsigned long long)) != hipSuccess) {
     delete sc;
@@ -789,12 +1035,33 @@ int rt_trace_rays(const rt_scene* scene, const rt_options* options, uint32_t n, 
       rc = fail(RT_ERR_DEVICE, "upload of rays failed");
       break;
     }
-    if (options->reference_order)
+    if (options->reference_order) {
       hipLaunchKernelGGL(trace_rays_kernel<true>, dim3((n + 63) / 64), dim3(64), 0, 0, scene->dev, dev_options(options), n, d_o, d_d,
                          d_c, scene->d_overflow);
-    else
+    } else if (options->pipeline == RT_PIPELINE_SINGLE_KERNEL) {
       hipLaunchKernelGGL(trace_rays_kernel<false>, dim3((n + 63) / 64), dim3(64), 0, 0, scene->dev, dev_options(options), n, d_o, d_d,
                          d_c, scene->d_overflow);
+    } else {  // the streamed pipeline with the given rays as its level-0 queue
+      uint32_t batch = 0;
+      rc = ensure_workspace(scene, n, &batch);
+      if (rc) break;
+      rt_camera no_cam;
+      std::memset(&no_cam, 0, sizeof(no_cam));
+      DevOptions dopt = dev_options(options);
+      for (uint32_t at = 0; at < n && rc == RT_OK; at += batch) {
+        stream::Batch b;
+        std::memset(&b, 0, sizeof(b));
+        b.n_parts = 1;
+        b.n2 = 1;
+        b.n_samples = std::min(batch, n - at);
+        b.given_o = d_o + (size_t)at * 3;
+        b.given_d = d_d + (size_t)at * 3;
+        rc = run_stream_batch<false, false>(scene, no_cam, dopt, b, 0);
+        if (rc == RT_OK && hipMemcpyAsync(d_c + (size_t)at * 3, scene->ws.sample_rgb, (size_t)b.n_samples * 24, hipMemcpyDeviceToDevice, 0) != hipSuccess)
+          rc = fail(RT_ERR_DEVICE, "copy of the traced colours failed");
+      }
+      if (rc) break;
+    }
     uint32_t ovf = 0;
     if (hipDeviceSynchronize() != hipSuccess || hipMemcpy(out_rgb, d_c, bytes, hipMemcpyDeviceToHost) != hipSuccess ||
         hipMemcpy(&ovf, scene->d_overflow, sizeof(ovf), hipMemcpyDeviceToHost) != hipSuccess) {

@@ -49,12 +49,21 @@ typedef hipEventRec* hipEvent_t;
 enum { hipSuccess = 0 };
 enum hipMemcpyKind { hipMemcpyHostToDevice, hipMemcpyDeviceToHost, hipMemcpyDeviceToDevice };
 static inline const char* hipGetErrorString(hipError_t) { return "host emulation"; }
+static inline uint32_t min(uint32_t a, uint32_t b) { return a < b ? a : b; }
+static inline uint32_t __builtin_amdgcn_mbcnt_lo(uint32_t, uint32_t v) { return v; }  // single lane: nothing below it
+static inline uint32_t __builtin_amdgcn_mbcnt_hi(uint32_t, uint32_t v) { return v; }
+static inline uint32_t __builtin_amdgcn_readfirstlane(uint32_t v) { return v; }
+static inline double __longlong_as_double(long long u) { double d; std::memcpy(&d, &u, 8); return d; }
+enum { hipDeviceAttributeMultiprocessorCount = 0 };
+static inline hipError_t hipDeviceGetAttribute(int* v, int, int) { *v = 1; return hipSuccess; }
+static inline hipError_t hipMemGetInfo(size_t* f, size_t* t) { *f = (size_t)6 << 30; *t = (size_t)8 << 30; return hipSuccess; }
 static inline hipError_t hipGetLastError() { return hipSuccess; }
 static inline hipError_t hipGetDeviceCount(int* n) { *n = 1; return hipSuccess; }
 static inline hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
 static inline hipError_t hipMalloc(void** p, size_t n) { *p = std::malloc(n); return hipSuccess; }
 static inline hipError_t hipFree(void* p) { std::free(p); return hipSuccess; }
 static inline hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { std::memcpy(d, s, n); return hipSuccess; }
+static inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t) { std::memcpy(d, s, n); return hipSuccess; }
 static inline hipError_t hipMemset(void* d, int v, size_t n) { std::memset(d, v, n); return hipSuccess; }
 static inline hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t) { std::memset(d, v, n); return hipSuccess; }
 static inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
