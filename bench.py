@@ -115,6 +115,7 @@ def main():
     flat = rs.builder.flatten()
     t_prep = time.perf_counter() - t0
     cam, opt = rs.camera, rs.options()
+    opt.pipeline = int(os.environ.get("RT_PIPELINE", "0"))  # development: 1 = the single-kernel core
     scene = R.DeviceScene(flat)  # upload: outside the timed region (inputs resident in HBM)
     stream = torch.cuda.current_stream().cuda_stream
 

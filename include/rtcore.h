@@ -188,6 +188,10 @@ typedef struct rt_stats {
                              surfaces coincide within 1e-10 (see DESIGN.md "Ties") */
   uint64_t clocks_traversal, clocks_machine; /* production traversal, statistics launches only: shader clocks summed over
                              lanes spent in the traversal loop / in the shading state machine */
+  uint64_t clocks_trace_total; /* streamed pipeline, statistics launches: wavefront clocks of the trace kernels from start to
+                              end, summed over wavefronts; there clocks_traversal = wavefront clocks in the node loop and
+                              clocks_machine = wavefront clocks in leaves (the rest: fetching rays, setting them up, storing
+                              results, and the drain after the queue is dry) */
   uint64_t fallback_flags; /* streamed pipeline: times a ray or hit found its batch's queues full; the samples concerned were
                               re-rendered by the single-kernel state machine (same pixels, slower).  0 in a well-sized batch */
   double ms_upload, ms_kernel, ms_download;

@@ -216,6 +216,9 @@ __device__ __forceinline__ uint32_t stack_pop(Trav& T, const uint2* lds, const u
   return RT_FREF_NONE;
 }
 
+__device__ __forceinline__ bool first_active_lane() {
+  return (uint32_t)(__ffsll((long long)__builtin_amdgcn_ballot_w64(true)) - 1) == (threadIdx.x & 63u);
+}
 __device__ __forceinline__ void count_step(Counters& cnt) {  // statistics builds only
   unsigned long long active = __builtin_amdgcn_ballot_w64(true);
   cnt.lane_steps++;
@@ -229,6 +232,7 @@ template <bool STATS, int MS = MS_ALL>
 __device__ __forceinline__ void trav_run(const DevScene& s, Trav& T, uint2* lds, uint2* ovf, Counters& cnt, uint32_t min_active = 0) {
   while (T.cur != RT_FREF_NONE) {
     if (min_active && (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(true)) < min_active) break;
+    unsigned long long tc0 = (STATS && min_active) ? (unsigned long long)clock64() : 0ull;
     // ---- inner nodes: descend until this lane holds a leaf (or runs out of work) ----
     while ((T.cur >> RT_FREF_KIND_SHIFT) == RT_FREF_INNER) {
       if (STATS) count_step(cnt);
@@ -272,6 +276,8 @@ __device__ __forceinline__ void trav_run(const DevScene& s, Trav& T, uint2* lds,
         T.cur = stack_pop(T, lds, ovf);
       }
     }
+    unsigned long long tc1 = (STATS && min_active) ? (unsigned long long)clock64() : 0ull;
+    if (STATS && min_active && first_active_lane()) cnt.cyc_trav += (uint32_t)((tc1 - tc0) >> 6);
     if (T.cur == RT_FREF_NONE) break;
     // ---- leaf ----
     if (STATS) count_step(cnt);
@@ -302,6 +308,7 @@ __device__ __forceinline__ void trav_run(const DevScene& s, Trav& T, uint2* lds,
         }
       }
     }
+    if (STATS && min_active && first_active_lane()) cnt.cyc_adv += (uint32_t)(((unsigned long long)clock64() - tc1) >> 6);
     if (in_mode<MS>(T, M_SHADOW) && T.a >= 1.) {  // min(intensity, 1) is already 1 (intersection.rs:124-126)
       T.cur = RT_FREF_NONE;
       T.sp = 0;

@@ -7,7 +7,9 @@ struct Counters {
   uint32_t rays_primary, rays_shadow, rays_reflect, rays_refract, node_visits, tri_tests, prim_tests, hits, hit_bytes, overflow;
   uint32_t wave_steps, lane_steps;  // fast path: traversal steps of the wavefront / lanes active in them
   uint32_t retraced;                // fast path: rays settled by the reference-order walk (coincident surfaces)
-  uint32_t cyc_trav, cyc_adv;       // fast path, statistics builds: shader clocks / 64 spent traversing / in the state machine
+  uint32_t cyc_trav, cyc_adv;       // statistics builds: shader clocks / 64 spent traversing / in the state machine (single kernel);
+                                    // wavefront clocks / 64 in the node loop / in leaves (streamed trace kernels)
+  uint32_t cyc_total;               // streamed trace kernels: wavefront clocks / 64 from the kernel's start to its end
 };
 
 // ---------------------------------------------------------------------------------------------

@@ -253,7 +253,8 @@ __global__ __launch_bounds__(64, RT_TRACE_WAVES) void trace_closest_kernel(DevSc
   __shared__ uint2 lds_stack[RT_LDS_STACK * 64];
   uint2* lds = lds_stack + (threadIdx.x & 63u);
   uint2 ovf[RT_OVF_STACK];
-  Counters cnt = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  Counters cnt = {};
+  const unsigned long long clk0 = STATS ? (unsigned long long)clock64() : 0ull;
   const uint32_t n_rays = level == 0 ? b.n_samples : w.ctrl->n_rays[level];
   const double* __restrict__ queue = w.rays[level & 1];
   fast::Trav T;
@@ -335,6 +336,7 @@ __global__ __launch_bounds__(64, RT_TRACE_WAVES) void trace_closest_kernel(DevSc
       }
     }
   }
+  if (STATS && (threadIdx.x & 63u) == 0) cnt.cyc_total += (uint32_t)(((unsigned long long)clock64() - clk0) >> 6);
   flush_counters<STATS>(cnt, stats, overflow_flag);
 }
 
@@ -346,7 +348,7 @@ __global__ __launch_bounds__(64, 2) void retrace_kernel(DevScene s, rt_camera ca
   __shared__ uint2 lds_stack[RT_LDS_STACK * 64];
   uint2* lds = lds_stack + (threadIdx.x & 63u);
   uint2 ovf[RT_OVF_STACK];
-  Counters cnt = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  Counters cnt = {};
   const uint32_t n = w.ctrl->n_retrace[level];
   const double* __restrict__ queue = w.rays[level & 1];
   for (uint32_t i = blockIdx.x * 64u + (threadIdx.x & 63u); i < n; i += gridDim.x * 64u) {
@@ -386,7 +388,7 @@ __global__ __launch_bounds__(64, 2) void retrace_kernel(DevScene s, rt_camera ca
 template <bool CAMERA, bool STATS>
 __global__ __launch_bounds__(256) void shade_kernel(DevScene s, rt_camera cam, DevOptions opt, Ws w, Batch b, uint32_t level,
                                                     unsigned long long* stats, uint32_t* overflow_flag) {
-  Counters cnt = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  Counters cnt = {};
   const uint32_t n_rays = level == 0 ? b.n_samples : w.ctrl->n_rays[level];
   const double* __restrict__ queue = w.rays[level & 1];
   double* __restrict__ next = w.rays[(level + 1) & 1];
@@ -513,7 +515,8 @@ __global__ __launch_bounds__(64, RT_TRACE_WAVES) void trace_shadow_kernel(DevSce
   __shared__ uint2 lds_stack[RT_LDS_STACK * 64];
   uint2* lds = lds_stack + (threadIdx.x & 63u);
   uint2 ovf[RT_OVF_STACK];
-  Counters cnt = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  Counters cnt = {};
+  const unsigned long long clk0 = STATS ? (unsigned long long)clock64() : 0ull;
   const uint32_t n_nodes = w.ctrl->n_nodes;
   const unsigned long long n_items = (unsigned long long)n_nodes * s.n_lights;
   const size_t cap = w.cap_nodes;
@@ -559,6 +562,7 @@ __global__ __launch_bounds__(64, RT_TRACE_WAVES) void trace_shadow_kernel(DevSce
       my = ~0ull;
     }
   }
+  if (STATS && (threadIdx.x & 63u) == 0) cnt.cyc_total += (uint32_t)(((unsigned long long)clock64() - clk0) >> 6);
   flush_counters<STATS>(cnt, stats, overflow_flag);
 }
 
@@ -619,7 +623,7 @@ __global__ __launch_bounds__(64, 2) void fallback_kernel(DevScene s, rt_camera c
   __shared__ uint2 lds_stack[RT_LDS_STACK * 64];
   if (w.ctrl->n_flagged == 0) return;
   if (stats && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&stats[RT_COUNTER_FALLBACK], (unsigned long long)w.ctrl->n_flagged);
-  Counters cnt = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  Counters cnt = {};
   const uint32_t lane = threadIdx.x & 63u;
   for (uint32_t wbase = blockIdx.x * 64u; wbase < b.n_samples; wbase += gridDim.x * 64u) {
     uint32_t id = wbase + lane;

@@ -17,7 +17,7 @@
 // ---------------------------------------------------------------------------------------------
 // kernels
 // ---------------------------------------------------------------------------------------------
-#define RT_N_COUNTERS 16
+#define RT_N_COUNTERS 17
 #define RT_COUNTER_FALLBACK 15  // streamed pipeline: flag events of samples handed to the fallback kernel
 #ifndef RT_WAVES_PER_EU
 #define RT_WAVES_PER_EU 2  // waves per SIMD the register allocator must leave room for (256 VGPRs: no spills; measured best)
@@ -27,13 +27,13 @@ template <bool STATS>
 __device__ __forceinline__ void flush_counters(const Counters& c, unsigned long long* stats, uint32_t* overflow_flag) {
   if (c.overflow) atomicOr(overflow_flag, 1u);
   if (!STATS) return;
-  uint32_t v[15] = {c.rays_primary, c.rays_shadow, c.rays_reflect, c.rays_refract, c.node_visits, c.tri_tests,
+  uint32_t v[16] = {c.rays_primary, c.rays_shadow, c.rays_reflect, c.rays_refract, c.node_visits, c.tri_tests,
                                c.prim_tests,   c.hits,        c.hit_bytes,    c.overflow,     c.wave_steps,  c.lane_steps,
-                               c.retraced,     c.cyc_trav,    c.cyc_adv};
-  for (int k = 0; k < 15; k++) {
+                               c.retraced,     c.cyc_trav,    c.cyc_adv,     c.cyc_total};
+  for (int k = 0; k < 16; k++) {
     unsigned long long x = v[k];
     for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
-    if ((threadIdx.x & 63) == 0 && x) atomicAdd(&stats[k], x);
+    if ((threadIdx.x & 63) == 0 && x) atomicAdd(&stats[k == 15 ? 16 : k], x);
   }
 }
 
@@ -94,7 +94,7 @@ __global__ __launch_bounds__(64, REFORDER ? 2 : RT_WAVES_PER_EU) void render_til
   uint32_t lane = threadIdx.x;
   uint32_t px = (tile % tiles_x) * RT_TILE_DIM + (lane & 7u);
   uint32_t py = (tile / tiles_x) * RT_TILE_DIM + (lane >> 3);
-  Counters cnt = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  Counters cnt = {};
   bool inside = px < cam.width && py < cam.height;
   d3 color = mk3(0., 0., 0.);
   if (REFORDER) {
@@ -179,7 +179,7 @@ __global__ __launch_bounds__(64, REFORDER ? 2 : RT_WAVES_PER_EU) void trace_rays
                                                                           uint32_t* overflow_flag) {
   __shared__ uint2 lds_stack[RT_LDS_STACK * 64];
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  Counters cnt = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  Counters cnt = {};
   bool valid = i < n;
   d3 o = mk3(0., 0., 0.), d = mk3(0., 0., 1.), c = mk3(0., 0., 0.);
   if (valid) {
@@ -828,6 +828,7 @@ int launch_render(const rt_scene* scene, const rt_camera* cam, const rt_options*
     stats->clocks_traversal = h[13] * 64;
     stats->clocks_machine = h[14] * 64;
     stats->fallback_flags = h[15];
+    stats->clocks_trace_total = h[16] * 64;
     stats->ms_kernel = ms;
     if (ovf) return fail(RT_ERR_OVERFLOW, "a per-ray bounded list (BVH stack or CSG hit list) overflowed on the device");
   }
