@@ -17,7 +17,7 @@
 //     retrace         those few rays, settled in the reference's own visiting order (rt_reforder.h).
 //     shade           IntersecComputations::new for every hit (intersection.rs:217-256): one NODE record per hit
 //                     (over point, eye, normal, n1, n2), plus the reflected / refracted rays of level l+1.
-//   trace_shadow      one shadow ray per (node, light) for all nodes of all levels (integrator.rs:136-152).
+//   trace_shadow      the shadow rays of every node of every level, one per light (integrator.rs:136-152).
 //   level l = max_depth..0:
 //     combine         shade_hit_at_depth's fold over the lights (integrator.rs:199-228) for every node of the level, in
 //                     the reference's operation order; the colour goes to the parent node's reflected / refracted slot,
@@ -48,12 +48,12 @@ enum { NU_PRIM = 0, NU_PARENT = 1, NU_ROOT = 2, NU_COUNT = 3 };
 
 struct Ctrl {  // device-resident control block of one batch; zeroed when the batch starts
   uint32_t n_rays[RT_LEVELS + 1];  // rays queued for each level (level 0: unused, its rays are the batch's samples)
-  unsigned long long fetch[RT_LEVELS][8];  // trace_closest: next ray of the level in each XCD's share (xcd_take)
+  uint32_t fetch[RT_LEVELS][8];    // trace_closest: next ray of the level in each XCD's share (xcd_take)
   uint32_t n_retrace[RT_LEVELS];
   uint32_t level_end[RT_LEVELS];   // nodes [level_end[l-1], level_end[l]) belong to level l
   uint32_t n_nodes;                // nodes allocated (may run past cap_nodes; clamped in level_end)
   uint32_t n_flagged;              // samples handed to the fallback
-  unsigned long long shadow_fetch[8];
+  uint32_t shadow_fetch[8];        // trace_shadow: next node in each XCD's share
 };
 
 struct Ws {  // workspace of one batch (device pointers; owned by rt_scene)
@@ -66,6 +66,7 @@ struct Ws {  // workspace of one batch (device pointers; owned by rt_scene)
   double* shadow;        // [n_lights][cap_nodes] accumulated shadow intensity (IntersectionCollector, intersection.rs:78-87)
   double* sample_rgb;    // [n_samples][3]
   uint8_t* sample_flag;  // [n_samples] 1: re-render this sample in the fallback kernel
+  uint32_t* tile_xy;     // [n_samples / 64] Batch::tile_xy
   uint32_t cap_rays, cap_nodes;
 };
 
@@ -77,6 +78,8 @@ struct Batch {
   uint32_t packed;
   const double* given_o;                     // rt_trace_rays: level 0 is these rays ([n_samples][3] each) instead of the camera's
   const double* given_d;
+  const uint32_t* tile_xy;                   // [n_tiles] tile x | tile y << 16 of each tile of the batch (tile_table_kernel)
+  unsigned long long n2_magic;               // floor(2^32 / n2) + 1: r / n2 == (r * n2_magic) >> 32 for r < 2^32 / n2
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -99,43 +102,25 @@ __device__ __forceinline__ uint32_t wave_take(uint32_t* counter, bool want) {
   }
   return id;
 }
-__device__ __forceinline__ unsigned long long wave_take64(unsigned long long* counter, bool want) {
-  unsigned long long m = __builtin_amdgcn_ballot_w64(want);
-  unsigned long long id = 0;
-  if (want) {
-    uint32_t r = rank_in(m), lo = 0, hi = 0;
-    if (r == 0) {
-      unsigned long long base = atomicAdd(counter, (unsigned long long)__builtin_popcountll(m));
-      lo = (uint32_t)base;
-      hi = (uint32_t)(base >> 32);
-    }
-    lo = __builtin_amdgcn_readfirstlane(lo);
-    hi = __builtin_amdgcn_readfirstlane(hi);
-    id = (((unsigned long long)hi << 32) | lo) + r;
-  }
-  return id;
-}
-
 // XCD-aware work distribution for the persistent trace kernels.  Workgroup ids are dealt round-robin to the 8 XCDs, each
 // with its own 4 MB L2, so the items (rays in queue order = image order) are cut into chunks of RT_XCD_CHUNK and chunk c
 // belongs to XCD c % 8: the rays in flight on one XCD then cover a compact patch of the image and walk the same BVH
 // subtrees, which its L2 can hold.  Each XCD has its own counter over its share; a wavefront whose XCD's share is used
-// up takes from the next XCD's (`victim`, wave-uniform, only ever advances).  Returns ~0 when nothing is left.
+// up takes from the next XCD's (`victim`, wave-uniform, only ever advances).  Returns RT_NONE when nothing is left.
 #ifndef RT_XCD_CHUNK
 #define RT_XCD_CHUNK 65536u
 #endif
-__device__ __forceinline__ unsigned long long xcd_take(unsigned long long* counters, unsigned long long n_items, uint32_t xcd,
-                                                       uint32_t& victim, bool want) {
-  unsigned long long id = ~0ull;
+__device__ __forceinline__ uint32_t xcd_take(uint32_t* counters, uint32_t n_items, uint32_t xcd, uint32_t& victim, bool want) {
+  uint32_t id = RT_NONE;
   while (victim < 8u) {
-    bool w = want && id == ~0ull;
+    bool w = want && id == RT_NONE;
     if (__builtin_amdgcn_ballot_w64(w) == 0ull) break;
     uint32_t xx = (xcd + victim) & 7u;
-    unsigned long long q = wave_take64(&counters[xx], w);
+    uint32_t q = wave_take(&counters[xx], w);
     bool failed = false;
     if (w) {
-      unsigned long long g = ((q / RT_XCD_CHUNK) * 8u + xx) * RT_XCD_CHUNK + q % RT_XCD_CHUNK;
-      if (g < n_items) id = g;
+      unsigned long long g = ((unsigned long long)(q / RT_XCD_CHUNK) * 8u + xx) * RT_XCD_CHUNK + q % RT_XCD_CHUNK;
+      if (g < n_items) id = (uint32_t)g;
       else failed = true;
     }
     if (__builtin_amdgcn_ballot_w64(failed) != 0ull) victim++;  // ids only grow: that share is used up
@@ -166,14 +151,24 @@ __device__ __forceinline__ uint32_t tile_packed_index(const Batch& b, uint32_t k
   return kpos;
 }
 
+// The tiles of a batch, looked up by the kernels instead of re-deriving the block order per ray.
+__global__ __launch_bounds__(256) void tile_table_kernel(Batch b, uint32_t* __restrict__ tile_xy) {
+  for (uint32_t tl = blockIdx.x * blockDim.x + threadIdx.x; tl < b.n_tiles; tl += gridDim.x * blockDim.x) {
+    uint32_t px, py;
+    tile_pixel(b, b.tile0 + tl, 0, px, py);
+    tile_xy[tl] = (px / RT_TILE_DIM) | ((py / RT_TILE_DIM) << 16);
+  }
+}
+
 // Sample id -> camera ray.  id = ((tile of the batch * n2) + sample k) * 64 + pixel slot, so 64 consecutive ids are one
 // sample of one 8x8 tile.  Camera::ray_for_pixel (camera.rs:189-201) at the offsets of renderer.rs:57-64 (dx outer).
 __device__ __forceinline__ bool camera_sample(const rt_camera& cam, const DevOptions& opt, const Batch& b, uint32_t id, d3& o, d3& d) {
-  uint32_t p = id & 63u, r = id >> 6, tl = r / b.n2, k = r - tl * b.n2;
-  uint32_t px, py;
-  tile_pixel(b, b.tile0 + tl, p, px, py);
+  uint32_t p = id & 63u, r = id >> 6, tl = (uint32_t)((r * b.n2_magic) >> 32), k = r - tl * b.n2;  // no integer division here
+  uint32_t xy = b.tile_xy[tl];
+  uint32_t px = (xy & 0xFFFFu) * RT_TILE_DIM + (p & 7u), py = (xy >> 16) * RT_TILE_DIM + (p >> 3);
   if (px >= cam.width || py >= cam.height) return false;  // ragged edge: no such pixel
-  uint32_t i = k / opt.n_offsets, j = k - i * opt.n_offsets;
+  uint32_t n = opt.n_offsets;
+  uint32_t i = (k >= n ? 1u : 0u) + (k >= 2 * n ? 1u : 0u) + (k >= 3 * n ? 1u : 0u) + (k >= 4 * n ? 1u : 0u), j = k - i * n;
   double ox = opt.offsets[0], oy = opt.offsets[0];
   for (uint32_t q = 1; q < 5; q++) {  // select, not index: the options live in scalar registers
     if (i == q) ox = opt.offsets[q];
@@ -270,10 +265,9 @@ __global__ __launch_bounds__(64, RT_TRACE_WAVES) void trace_closest_kernel(DevSc
     // ---- idle lanes take the next rays of the level ----
     bool want = my == RT_NONE && !exhausted;
     if (__builtin_amdgcn_ballot_w64(want) != 0ull) {
-      unsigned long long got = xcd_take(w.ctrl->fetch[level], n_rays, blockIdx.x & 7u, victim, want);
+      uint32_t id = xcd_take(w.ctrl->fetch[level], n_rays, blockIdx.x & 7u, victim, want);
       if (want) {
-        if (got != ~0ull) {
-          uint32_t id = (uint32_t)got;
+        if (id != RT_NONE) {
           d3 o, d;
           bool ok = true;
           if (level == 0) {
@@ -506,9 +500,17 @@ __global__ void close_level_kernel(Ws w, uint32_t level) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// trace_shadow: Integrator::point_shadow_intensity_comps (integrator.rs:136-152) for every (node, light) pair.
-// Item id = light * n_nodes + node: a wavefront's lanes hold neighbouring nodes and the same light.
+// trace_shadow: Integrator::point_shadow_intensity_comps (integrator.rs:136-152) for every node and every light.
+// A lane takes a NODE and traces its shadow rays one light after the other (the origin, over_point, stays in registers).
 // ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void shadow_start(const DevScene& s, fast::Trav& T, d3 over, uint32_t l) {
+  const double* lp = s.light_pos + (size_t)l * 3;
+  d3 vv = sub3(mk3(lp[0], lp[1], lp[2]), over);  // get_point_shadow_dist_ray (integrator.rs:110-123)
+  double dist = mag3(vv);
+  d3 sdir = normalize3(vv);
+  fast::trav_start(T, over, sdir, fast::M_SHADOW, dist);
+}
+
 template <bool STATS>
 __global__ __launch_bounds__(64, RT_TRACE_WAVES) void trace_shadow_kernel(DevScene s, Ws w, unsigned long long* stats,
                                                                          uint32_t* overflow_flag) {
@@ -517,8 +519,7 @@ __global__ __launch_bounds__(64, RT_TRACE_WAVES) void trace_shadow_kernel(DevSce
   uint2 ovf[RT_OVF_STACK];
   Counters cnt = {};
   const unsigned long long clk0 = STATS ? (unsigned long long)clock64() : 0ull;
-  const uint32_t n_nodes = w.ctrl->n_nodes;
-  const unsigned long long n_items = (unsigned long long)n_nodes * s.n_lights;
+  const uint32_t n_nodes = s.n_lights ? w.ctrl->n_nodes : 0u;
   const size_t cap = w.cap_nodes;
   fast::Trav T;
   T.cur = RT_FREF_NONE;
@@ -526,25 +527,21 @@ __global__ __launch_bounds__(64, RT_TRACE_WAVES) void trace_shadow_kernel(DevSce
   T.mode = fast::M_SHADOW;
   T.limit = 0.;
   T.a = 0.;
-  unsigned long long my = ~0ull;
+  uint32_t my = RT_NONE, light = 0;  // the node this lane is working on, and the light of its current ray
   bool exhausted = false;
   uint32_t victim = 0;
   for (;;) {
-    bool want = my == ~0ull && !exhausted;
+    bool want = my == RT_NONE && !exhausted;
     if (__builtin_amdgcn_ballot_w64(want) != 0ull) {
-      unsigned long long id = xcd_take(w.ctrl->shadow_fetch, n_items, blockIdx.x & 7u, victim, want);
+      uint32_t id = xcd_take(w.ctrl->shadow_fetch, n_nodes, blockIdx.x & 7u, victim, want);
       if (want) {
-        if (id != ~0ull) {
-          uint32_t l = (uint32_t)(id / n_nodes), node = (uint32_t)(id - (unsigned long long)l * n_nodes);
-          const double* nf = w.node_f + node;
+        if (id != RT_NONE) {
+          const double* nf = w.node_f + id;
           d3 over = mk3(nf[(NF_OVER + 0) * cap], nf[(NF_OVER + 1) * cap], nf[(NF_OVER + 2) * cap]);
-          const double* lp = s.light_pos + (size_t)l * 3;
-          d3 vv = sub3(mk3(lp[0], lp[1], lp[2]), over);  // get_point_shadow_dist_ray (integrator.rs:110-123)
-          double dist = mag3(vv);
-          d3 sdir = normalize3(vv);
           if (STATS) cnt.rays_shadow++;
           my = id;
-          fast::trav_start(T, over, sdir, fast::M_SHADOW, dist);
+          light = 0;
+          shadow_start(s, T, over, 0);
         } else {
           exhausted = true;
         }
@@ -556,10 +553,15 @@ __global__ __launch_bounds__(64, RT_TRACE_WAVES) void trace_shadow_kernel(DevSce
     }
     uint32_t min_active = __builtin_amdgcn_ballot_w64(exhausted) != 0ull ? 0u : (uint32_t)RT_REFILL_BELOW;
     fast::trav_run<STATS, fast::MS_SHADOW>(s, T, lds, ovf, cnt, min_active);
-    if (my != ~0ull && T.cur == RT_FREF_NONE) {
-      uint32_t l = (uint32_t)(my / n_nodes), node = (uint32_t)(my - (unsigned long long)l * n_nodes);
-      w.shadow[(size_t)l * cap + node] = T.a;
-      my = ~0ull;
+    if (my != RT_NONE && T.cur == RT_FREF_NONE) {
+      w.shadow[(size_t)light * cap + my] = T.a;
+      light++;
+      if (light < s.n_lights) {
+        if (STATS) cnt.rays_shadow++;
+        shadow_start(s, T, T.o, light);
+      } else {
+        my = RT_NONE;
+      }
     }
   }
   if (STATS && (threadIdx.x & 63u) == 0) cnt.cyc_total += (uint32_t)(((unsigned long long)clock64() - clk0) >> 6);
@@ -652,8 +654,8 @@ __global__ __launch_bounds__(256) void resolve_kernel(rt_camera cam, Ws w, Batch
   const double nn = (double)b.n2;
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_pixels; i += gridDim.x * blockDim.x) {
     uint32_t tl = i >> 6, p = i & 63u;
-    uint32_t px, py;
-    tile_pixel(b, b.tile0 + tl, p, px, py);
+    uint32_t xy = b.tile_xy[tl];
+    uint32_t px = (xy & 0xFFFFu) * RT_TILE_DIM + (p & 7u), py = (xy >> 16) * RT_TILE_DIM + (p >> 3);
     bool inside = px < cam.width && py < cam.height;
     d3 color = mk3(0., 0., 0.);
     if (inside) {

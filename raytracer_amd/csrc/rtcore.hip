@@ -609,6 +609,7 @@ DevOptions dev_options(const rt_options* o) {
 int check_render_args(const rt_scene* scene, const rt_camera* cam, const rt_options* opt) {
   if (!scene || !cam || !opt) return fail(RT_ERR_INVALID_ARGUMENT, "scene, camera and options are required");
   if (cam->width == 0 || cam->height == 0) return fail(RT_ERR_INVALID_ARGUMENT, "camera width/height must be > 0");
+  if (cam->width > (1u << 19) || cam->height > (1u << 19)) return fail(RT_ERR_UNSUPPORTED, "camera width/height above 524288");
   if (opt->n_offsets < 1 || opt->n_offsets > 5) return fail(RT_ERR_INVALID_ARGUMENT, "n_offsets must be 1..5");
   if (opt->max_depth > RT_MAX_DEPTH)
     return fail(RT_ERR_UNSUPPORTED, "max_depth exceeds the device limit RT_MAX_DEPTH (16)");
@@ -632,7 +633,7 @@ size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 // shadow results, the sample's colour and flag.
 size_t ws_bytes_per_sample(uint32_t n_lights) {
   return 2 * RT_RAY_STRIDE * 8 + RT_HIT_STRIDE * 8 + 4 +
-         RT_STREAM_NODES_PER_SAMPLE * (stream::NF_COUNT * 8 + stream::NU_COUNT * 4 + (size_t)n_lights * 8) + 24 + 1;
+         RT_STREAM_NODES_PER_SAMPLE * (stream::NF_COUNT * 8 + stream::NU_COUNT * 4 + (size_t)n_lights * 8) + 24 + 1 + 1;
 }
 
 // Makes sure the scene's workspace holds batches of min(want, limit) samples.  limit: RT_STREAM_BATCH_SAMPLES (default
@@ -665,7 +666,7 @@ int ensure_workspace(const rt_scene* sc, uint64_t want_samples, uint32_t* batch_
   }
   const size_t A = 256;
   uint32_t cap_rays = (uint32_t)n, cap_nodes = RT_STREAM_NODES_PER_SAMPLE * (uint32_t)n;
-  size_t off = 0, o_ctrl, o_rays0, o_rays1, o_hits, o_retrace, o_nf, o_nu, o_shadow, o_rgb, o_flag;
+  size_t off = 0, o_ctrl, o_rays0, o_rays1, o_hits, o_retrace, o_nf, o_nu, o_shadow, o_rgb, o_flag, o_tiles;
   auto take = [&](size_t bytes) {
     size_t at = off;
     off = align_up(off + bytes, A);
@@ -681,6 +682,7 @@ int ensure_workspace(const rt_scene* sc, uint64_t want_samples, uint32_t* batch_
   o_shadow = take((size_t)cap_nodes * std::max<uint32_t>(sc->n_lights, 1u) * 8);
   o_rgb = take((size_t)n * 24);
   o_flag = take((size_t)n);
+  o_tiles = take((size_t)n / 64 * 4 + 4);
   void* base = nullptr;
   if (hipMalloc(&base, off) != hipSuccess)
     return fail(RT_ERR_DEVICE, "hipMalloc of the render workspace (" + std::to_string(off >> 20) + " MiB) failed");
@@ -698,6 +700,7 @@ int ensure_workspace(const rt_scene* sc, uint64_t want_samples, uint32_t* batch_
   sc->ws.shadow = (double*)(b + o_shadow);
   sc->ws.sample_rgb = (double*)(b + o_rgb);
   sc->ws.sample_flag = (uint8_t*)(b + o_flag);
+  sc->ws.tile_xy = (uint32_t*)(b + o_tiles);
   sc->ws.cap_rays = cap_rays;
   sc->ws.cap_nodes = cap_nodes;
   *batch_samples = (uint32_t)std::min<uint64_t>(n, std::max<uint64_t>(align_up(want_samples, 64), 64));
@@ -754,6 +757,10 @@ int launch_stream_render(const rt_scene* sc, const rt_camera* cam, const DevOpti
     b.n_samples = b.n_tiles * per_tile;
     b.packed = (uint32_t)packed;
     b.given_o = b.given_d = nullptr;
+    b.tile_xy = sc->ws.tile_xy;
+    b.n2_magic = (1ull << 32) / n2 + 1;
+    hipLaunchKernelGGL(stream::tile_table_kernel, dim3(std::max(1u, std::min(1024u, (b.n_tiles + 255u) / 256u))), dim3(256), 0, st, b,
+                       sc->ws.tile_xy);
     rc = run_stream_batch<true, STATS>(sc, *cam, dopt, b, st);
     if (rc) return rc;
     uint32_t grid = std::max(1u, std::min((uint32_t)sc->n_cus * 8u, (b.n_tiles * 64u + 255u) / 256u));
