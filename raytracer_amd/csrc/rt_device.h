@@ -76,11 +76,13 @@ __device__ __forceinline__ d3 mat_transposed_vector(const double* __restrict__ m
 #define RT_FREF_NONE 0xFFFFFFFFu  // kind EMPTY: nothing left to visit
 #define RT_MAKE_FREF(kind, count, index) (((uint32_t)(kind) << RT_FREF_KIND_SHIFT) | ((uint32_t)(count) << RT_FREF_COUNT_SHIFT) | (uint32_t)(index))
 
-#define RT_NODE_WIDTH 4
-struct __attribute__((aligned(128))) DevNode {
+#ifndef RT_NODE_WIDTH
+#define RT_NODE_WIDTH 4  // 2 or 4 (2: the reference's binary tree as it is, 64-B nodes)
+#endif
+struct __attribute__((aligned(32 * RT_NODE_WIDTH))) DevNode {
   float bb[RT_NODE_WIDTH][6];   // child boxes: min x,y,z (rounded down), max x,y,z (rounded up) (bounding_box.rs:25-28)
   uint32_t ref[RT_NODE_WIDTH];  // RT_MAKE_FREF; unused slots hold RT_FREF_NONE and come last
-  uint32_t pad[4];
+  uint32_t pad[RT_NODE_WIDTH];
 };
 
 // Triangles are stored in leaf order, RT_TRI_STRIDE doubles each (80 B, 16-B aligned): p1, e1, e2, then the

@@ -279,15 +279,16 @@ __device__ __forceinline__ void trav_run(const DevScene& s, Trav& T, uint2* lds,
     key[a] = ka; key[b] = kb; ref[a] = ra; ref[b] = rb;  \
   }
       RT_CSWAP(0, 1)
+#if RT_NODE_WIDTH == 4
       RT_CSWAP(2, 3)
       RT_CSWAP(0, 2)
       RT_CSWAP(1, 3)
       RT_CSWAP(1, 2)
+#endif
 #undef RT_CSWAP
       if (key[0] < INFINITY) {
-        if (key[3] < INFINITY) stack_push(T, lds, ovf, ref[3], key[3], cnt);  // farthest deepest
-        if (key[2] < INFINITY) stack_push(T, lds, ovf, ref[2], key[2], cnt);
-        if (key[1] < INFINITY) stack_push(T, lds, ovf, ref[1], key[1], cnt);
+        for (int c = RT_NODE_WIDTH - 1; c > 0; c--)  // farthest deepest
+          if (key[c] < INFINITY) stack_push(T, lds, ovf, ref[c], key[c], cnt);
         T.cur = ref[0];
       } else {
         T.cur = stack_pop(T, lds, ovf);

@@ -17,7 +17,7 @@
 //     retrace         those few rays, settled in the reference's own visiting order (rt_reforder.h).
 //     shade           IntersecComputations::new for every hit (intersection.rs:217-256): one NODE record per hit
 //                     (over point, eye, normal, n1, n2), plus the reflected / refracted rays of level l+1.
-//   trace_shadow      the shadow rays of every node of every level, one per light (integrator.rs:136-152).
+//   trace_shadow      one shadow ray per (node, light) for all nodes of all levels (integrator.rs:136-152).
 //   level l = max_depth..0:
 //     combine         shade_hit_at_depth's fold over the lights (integrator.rs:199-228) for every node of the level, in
 //                     the reference's operation order; the colour goes to the parent node's reflected / refracted slot,
@@ -53,7 +53,7 @@ struct Ctrl {  // device-resident control block of one batch; zeroed when the ba
   uint32_t level_end[RT_LEVELS];   // nodes [level_end[l-1], level_end[l]) belong to level l
   uint32_t n_nodes;                // nodes allocated (may run past cap_nodes; clamped in level_end)
   uint32_t n_flagged;              // samples handed to the fallback
-  uint32_t shadow_fetch[8];        // trace_shadow: next node in each XCD's share
+  uint32_t shadow_fetch[8];        // trace_shadow: next (light, node) item in each XCD's share
 };
 
 struct Ws {  // workspace of one batch (device pointers; owned by rt_scene)
@@ -500,8 +500,9 @@ __global__ void close_level_kernel(Ws w, uint32_t level) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// trace_shadow: Integrator::point_shadow_intensity_comps (integrator.rs:136-152) for every node and every light.
-// A lane takes a NODE and traces its shadow rays one light after the other (the origin, over_point, stays in registers).
+// trace_shadow: Integrator::point_shadow_intensity_comps (integrator.rs:136-152) for every (node, light) pair.
+// Item id = light * n_nodes + node: a wavefront's lanes hold neighbouring nodes and the same light (a lane that walked
+// through its node's lights in turn was measured 10 % slower: the lanes of a wavefront then face different lights).
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ void shadow_start(const DevScene& s, fast::Trav& T, d3 over, uint32_t l) {
   const double* lp = s.light_pos + (size_t)l * 3;
@@ -519,7 +520,7 @@ __global__ __launch_bounds__(64, RT_TRACE_WAVES) void trace_shadow_kernel(DevSce
   uint2 ovf[RT_OVF_STACK];
   Counters cnt = {};
   const unsigned long long clk0 = STATS ? (unsigned long long)clock64() : 0ull;
-  const uint32_t n_nodes = s.n_lights ? w.ctrl->n_nodes : 0u;
+  const uint32_t n_nodes = w.ctrl->n_nodes, n_items = n_nodes * s.n_lights;  // (< 2^32: ensure_workspace)
   const size_t cap = w.cap_nodes;
   fast::Trav T;
   T.cur = RT_FREF_NONE;
@@ -533,15 +534,15 @@ __global__ __launch_bounds__(64, RT_TRACE_WAVES) void trace_shadow_kernel(DevSce
   for (;;) {
     bool want = my == RT_NONE && !exhausted;
     if (__builtin_amdgcn_ballot_w64(want) != 0ull) {
-      uint32_t id = xcd_take(w.ctrl->shadow_fetch, n_nodes, blockIdx.x & 7u, victim, want);
+      uint32_t id = xcd_take(w.ctrl->shadow_fetch, n_items, blockIdx.x & 7u, victim, want);
       if (want) {
         if (id != RT_NONE) {
-          const double* nf = w.node_f + id;
+          light = id / n_nodes;
+          my = id - light * n_nodes;
+          const double* nf = w.node_f + my;
           d3 over = mk3(nf[(NF_OVER + 0) * cap], nf[(NF_OVER + 1) * cap], nf[(NF_OVER + 2) * cap]);
           if (STATS) cnt.rays_shadow++;
-          my = id;
-          light = 0;
-          shadow_start(s, T, over, 0);
+          shadow_start(s, T, over, light);
         } else {
           exhausted = true;
         }
@@ -555,13 +556,7 @@ __global__ __launch_bounds__(64, RT_TRACE_WAVES) void trace_shadow_kernel(DevSce
     fast::trav_run<STATS, fast::MS_SHADOW>(s, T, lds, ovf, cnt, min_active);
     if (my != RT_NONE && T.cur == RT_FREF_NONE) {
       w.shadow[(size_t)light * cap + my] = T.a;
-      light++;
-      if (light < s.n_lights) {
-        if (STATS) cnt.rays_shadow++;
-        shadow_start(s, T, T.o, light);
-      } else {
-        my = RT_NONE;
-      }
+      my = RT_NONE;
     }
   }
   if (STATS && (threadIdx.x & 63u) == 0) cnt.cyc_total += (uint32_t)(((unsigned long long)clock64() - clk0) >> 6);
@@ -621,10 +616,14 @@ __global__ __launch_bounds__(256) void combine_kernel(DevScene s, DevOptions opt
 // Samples whose ray tree did not fit the batch's queues: rendered by the single-kernel state machine (rt_fast.h).
 template <bool CAMERA>
 __global__ __launch_bounds__(64, 2) void fallback_kernel(DevScene s, rt_camera cam, DevOptions opt, Ws w, Batch b,
-                                                         unsigned long long* stats, uint32_t* overflow_flag) {
+                                                         unsigned long long* stats, uint32_t* summary,
+                                                         uint32_t* overflow_flag) {
   __shared__ uint2 lds_stack[RT_LDS_STACK * 64];
   if (w.ctrl->n_flagged == 0) return;
-  if (stats && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&stats[RT_COUNTER_FALLBACK], (unsigned long long)w.ctrl->n_flagged);
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    atomicAdd(summary, w.ctrl->n_flagged);
+    if (stats) atomicAdd(&stats[RT_COUNTER_FALLBACK], (unsigned long long)w.ctrl->n_flagged);
+  }
   Counters cnt = {};
   const uint32_t lane = threadIdx.x & 63u;
   for (uint32_t wbase = blockIdx.x * 64u; wbase < b.n_samples; wbase += gridDim.x * 64u) {

@@ -249,8 +249,18 @@ struct rt_scene {
   mutable size_t ws_bytes = 0;
   mutable uint32_t ws_samples = 0;  // batch capacity in samples
   mutable stream::Ws ws{};
+  // node records per sample the batches are laid out for.  A sample whose ray tree needs more is re-rendered by the
+  // fallback kernel (same pixels, slower); the count of such events comes back with every frame and doubles this.
+  mutable uint32_t nodes_per_sample = 3;
+  mutable uint32_t* d_summary = nullptr;  // [1] fallback flags of the frame in flight
+  mutable uint32_t* h_summary = nullptr;  // pinned copy, valid once summary_event has completed
+  mutable hipEvent_t summary_event = nullptr;
+  mutable bool summary_pending = false;
   ~rt_scene() {
     if (ws_base) (void)hipFree(ws_base);
+    if (d_summary) (void)hipFree(d_summary);
+    if (h_summary) (void)hipHostFree(h_summary);
+    if (summary_event) (void)hipEventDestroy(summary_event);
   }
 };
 
@@ -627,83 +637,119 @@ uint32_t tiles_total(uint32_t w, uint32_t h, uint32_t* tiles_x) {
 // The streamed pipeline (rt_stream.h): workspace and launch sequence
 // ---------------------------------------------------------------------------------------------
 size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
-#define RT_STREAM_NODES_PER_SAMPLE 3u  // node records per sample of a batch; a sample that needs more goes to the fallback
+#define RT_STREAM_RATIO_MAX 64u
 
-// Bytes of workspace per sample of a batch: two ray queues, hit records, retrace list, 3 nodes' worth of node tables and
-// shadow results, the sample's colour and flag.
-size_t ws_bytes_per_sample(uint32_t n_lights) {
-  return 2 * RT_RAY_STRIDE * 8 + RT_HIT_STRIDE * 8 + 4 +
-         RT_STREAM_NODES_PER_SAMPLE * (stream::NF_COUNT * 8 + stream::NU_COUNT * 4 + (size_t)n_lights * 8) + 24 + 1 + 1;
+// Capacities of a batch of n samples laid out for `ratio` node records per sample: rays per level, nodes.
+void batch_caps(uint64_t n, uint32_t ratio, uint64_t* cap_rays, uint64_t* cap_nodes) {
+  *cap_nodes = n * ratio;
+  *cap_rays = n * std::max(1u, ratio / 2);  // a level's rays are at most twice the nodes of the level above
 }
 
-// Makes sure the scene's workspace holds batches of min(want, limit) samples.  limit: RT_STREAM_BATCH_SAMPLES (default
-// 32 Mi samples), and never more than a third of the device's free memory.
-int ensure_workspace(const rt_scene* sc, uint64_t want_samples, uint32_t* batch_samples) {
-  uint64_t limit = 32ull << 20;
-  if (const char* e = std::getenv("RT_STREAM_BATCH_SAMPLES")) {
-    unsigned long long v = std::strtoull(e, nullptr, 10);
-    if (v >= 64) limit = v;
-  }
-  if (limit > (1ull << 30)) limit = 1ull << 30;  // node ids carry two flag bits
-  uint64_t n = std::min<uint64_t>(want_samples, limit);
-  n = std::max<uint64_t>(align_up(n, 64), 64);
-  if (sc->ws_base && sc->ws_samples >= n) {
-    *batch_samples = (uint32_t)std::min<uint64_t>(sc->ws_samples, std::max<uint64_t>(align_up(want_samples, 64), 64));
-    return RT_OK;
-  }
-  size_t per = ws_bytes_per_sample(sc->n_lights);
-  size_t free_b = 0, total_b = 0;
-  if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b > 0) {
-    uint64_t fit = (free_b / 3 + sc->ws_bytes) / (per + 64);
-    if (fit < 4096) return fail(RT_ERR_DEVICE, "not enough free device memory for the render workspace");
-    if (n > fit) n = fit / 64 * 64;
-  }
-  if (sc->ws_base) {
-    (void)hipFree(sc->ws_base);
-    sc->ws_base = nullptr;
-    sc->ws_bytes = 0;
-    sc->ws_samples = 0;
-  }
+// Carves the workspace for batches of n samples; returns the bytes needed (and sets the pointers when base != NULL).
+size_t carve_workspace(stream::Ws* w, char* base, uint64_t n, uint32_t ratio, uint32_t n_lights) {
   const size_t A = 256;
-  uint32_t cap_rays = (uint32_t)n, cap_nodes = RT_STREAM_NODES_PER_SAMPLE * (uint32_t)n;
-  size_t off = 0, o_ctrl, o_rays0, o_rays1, o_hits, o_retrace, o_nf, o_nu, o_shadow, o_rgb, o_flag, o_tiles;
+  uint64_t cap_rays, cap_nodes;
+  batch_caps(n, ratio, &cap_rays, &cap_nodes);
+  size_t off = 0;
   auto take = [&](size_t bytes) {
     size_t at = off;
     off = align_up(off + bytes, A);
     return at;
   };
-  o_ctrl = take(sizeof(stream::Ctrl));
-  o_rays0 = take((size_t)cap_rays * RT_RAY_STRIDE * 8);
-  o_rays1 = take((size_t)cap_rays * RT_RAY_STRIDE * 8);
-  o_hits = take((size_t)n * RT_HIT_STRIDE * 8);
-  o_retrace = take((size_t)n * 4);
-  o_nf = take((size_t)cap_nodes * stream::NF_COUNT * 8);
-  o_nu = take((size_t)cap_nodes * stream::NU_COUNT * 4);
-  o_shadow = take((size_t)cap_nodes * std::max<uint32_t>(sc->n_lights, 1u) * 8);
-  o_rgb = take((size_t)n * 24);
-  o_flag = take((size_t)n);
-  o_tiles = take((size_t)n / 64 * 4 + 4);
-  void* base = nullptr;
-  if (hipMalloc(&base, off) != hipSuccess)
-    return fail(RT_ERR_DEVICE, "hipMalloc of the render workspace (" + std::to_string(off >> 20) + " MiB) failed");
-  char* b = (char*)base;
-  sc->ws_base = base;
-  sc->ws_bytes = off;
+  size_t o_ctrl = take(sizeof(stream::Ctrl));
+  size_t o_rays0 = take((size_t)cap_rays * RT_RAY_STRIDE * 8);
+  size_t o_rays1 = take((size_t)cap_rays * RT_RAY_STRIDE * 8);
+  size_t o_hits = take((size_t)cap_rays * RT_HIT_STRIDE * 8);
+  size_t o_retrace = take((size_t)cap_rays * 4);
+  size_t o_nf = take((size_t)cap_nodes * stream::NF_COUNT * 8);
+  size_t o_nu = take((size_t)cap_nodes * stream::NU_COUNT * 4);
+  size_t o_shadow = take((size_t)cap_nodes * std::max<uint32_t>(n_lights, 1u) * 8);
+  size_t o_rgb = take((size_t)n * 24);
+  size_t o_flag = take((size_t)n);
+  size_t o_tiles = take((size_t)n / 64 * 4 + 4);
+  if (base) {
+    w->ctrl = (stream::Ctrl*)(base + o_ctrl);
+    w->rays[0] = (double*)(base + o_rays0);
+    w->rays[1] = (double*)(base + o_rays1);
+    w->hits = (double*)(base + o_hits);
+    w->retrace = (uint32_t*)(base + o_retrace);
+    w->node_f = (double*)(base + o_nf);
+    w->node_u = (uint32_t*)(base + o_nu);
+    w->shadow = (double*)(base + o_shadow);
+    w->sample_rgb = (double*)(base + o_rgb);
+    w->sample_flag = (uint8_t*)(base + o_flag);
+    w->tile_xy = (uint32_t*)(base + o_tiles);
+    w->cap_rays = (uint32_t)cap_rays;
+    w->cap_nodes = (uint32_t)cap_nodes;
+  }
+  return off;
+}
+
+// Takes in the fallback count of the previous frame, if it has arrived: batches that overflowed get twice the node records.
+void absorb_summary(const rt_scene* sc) {
+  if (!sc->summary_pending || hipEventQuery(sc->summary_event) != hipSuccess) return;
+  sc->summary_pending = false;
+  if (sc->h_summary[0] > 0 && sc->nodes_per_sample < RT_STREAM_RATIO_MAX) sc->nodes_per_sample *= 2;
+}
+
+// Lays the scene's workspace out for batches of up to min(want, limit) samples at the scene's current nodes-per-sample
+// ratio, (re)allocating when it is too small.  limit: RT_STREAM_BATCH_SAMPLES (default 32 Mi samples), and the workspace
+// never takes more than a third of the device's free memory.
+int ensure_workspace(const rt_scene* sc, uint64_t want_samples, uint32_t* batch_samples) {
+  if (!sc->d_summary) {
+    if (hipMalloc((void**)&sc->d_summary, 16) != hipSuccess || hipMemset(sc->d_summary, 0, 16) != hipSuccess ||
+        hipHostMalloc((void**)&sc->h_summary, 16) != hipSuccess || hipEventCreate(&sc->summary_event) != hipSuccess)
+      return fail(RT_ERR_DEVICE, "allocation of the frame summary failed");
+    sc->h_summary[0] = 0;
+  }
+  absorb_summary(sc);
+  const uint32_t ratio = sc->nodes_per_sample;
+  uint64_t limit = 32ull << 20;
+  if (const char* e = std::getenv("RT_STREAM_BATCH_SAMPLES")) {
+    unsigned long long v = std::strtoull(e, nullptr, 10);
+    if (v >= 64) limit = v;
+  }
+  // node ids carry two flag bits, and (node, light) items are counted in 32 bits
+  limit = std::min<uint64_t>(limit, ((1ull << 30) / ratio) / std::max<uint32_t>(sc->n_lights, 1u));
+  uint64_t n = std::max<uint64_t>(align_up(std::min<uint64_t>(want_samples, limit), 64), 64);
+  size_t need = carve_workspace(nullptr, nullptr, n, ratio, sc->n_lights);
+  if (need > sc->ws_bytes) {
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b > 0) {
+      size_t budget = free_b / 3 + sc->ws_bytes;
+      while (need > budget && n > 4096) {
+        n = align_up(n / 2, 64);
+        need = carve_workspace(nullptr, nullptr, n, ratio, sc->n_lights);
+      }
+      if (need > budget) return fail(RT_ERR_DEVICE, "not enough free device memory for the render workspace");
+    }
+  }
+  if (need > sc->ws_bytes) {
+    if (sc->ws_base) {
+      (void)hipDeviceSynchronize();  // a frame may still be using it
+      (void)hipFree(sc->ws_base);
+      sc->ws_base = nullptr;
+      sc->ws_bytes = 0;
+    }
+    void* base = nullptr;
+    if (hipMalloc(&base, need) != hipSuccess)
+      return fail(RT_ERR_DEVICE, "hipMalloc of the render workspace (" + std::to_string(need >> 20) + " MiB) failed");
+    sc->ws_base = base;
+    sc->ws_bytes = need;
+  }
+  carve_workspace(&sc->ws, (char*)sc->ws_base, n, ratio, sc->n_lights);
   sc->ws_samples = (uint32_t)n;
-  sc->ws.ctrl = (stream::Ctrl*)(b + o_ctrl);
-  sc->ws.rays[0] = (double*)(b + o_rays0);
-  sc->ws.rays[1] = (double*)(b + o_rays1);
-  sc->ws.hits = (double*)(b + o_hits);
-  sc->ws.retrace = (uint32_t*)(b + o_retrace);
-  sc->ws.node_f = (double*)(b + o_nf);
-  sc->ws.node_u = (uint32_t*)(b + o_nu);
-  sc->ws.shadow = (double*)(b + o_shadow);
-  sc->ws.sample_rgb = (double*)(b + o_rgb);
-  sc->ws.sample_flag = (uint8_t*)(b + o_flag);
-  sc->ws.tile_xy = (uint32_t*)(b + o_tiles);
-  sc->ws.cap_rays = cap_rays;
-  sc->ws.cap_nodes = cap_nodes;
-  *batch_samples = (uint32_t)std::min<uint64_t>(n, std::max<uint64_t>(align_up(want_samples, 64), 64));
+  *batch_samples = (uint32_t)n;
+  return RT_OK;
+}
+
+// After the last batch of a frame: its fallback count travels to the host without stalling anything.
+int post_summary(const rt_scene* sc, hipStream_t st) {
+  if (sc->summary_pending) return RT_OK;  // the previous one has not been read yet; this frame's count is dropped
+  HIP_TRY(hipMemcpyAsync(sc->h_summary, sc->d_summary, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipMemsetAsync(sc->d_summary, 0, sizeof(uint32_t), st));
+  HIP_TRY(hipEventRecord(sc->summary_event, st));
+  sc->summary_pending = true;
   return RT_OK;
 }
 
@@ -731,7 +777,7 @@ int run_stream_batch(const rt_scene* sc, const rt_camera& cam, const DevOptions&
   for (uint32_t level = dopt.max_depth + 1; level-- > 0;)
     hipLaunchKernelGGL(stream::combine_kernel, dim3(wide_grid), dim3(256), 0, st, sc->dev, dopt, w, level);
   hipLaunchKernelGGL((stream::fallback_kernel<CAMERA>), dim3((uint32_t)sc->n_cus * 8u), dim3(64), 0, st, sc->dev, cam, dopt, w, b,
-                     STATS ? sc->d_stats : nullptr, sc->d_overflow);
+                     STATS ? sc->d_stats : nullptr, sc->d_summary, sc->d_overflow);
   HIP_TRY(hipGetLastError());
   return RT_OK;
 }
@@ -767,11 +813,11 @@ int launch_stream_render(const rt_scene* sc, const rt_camera* cam, const DevOpti
     hipLaunchKernelGGL(stream::resolve_kernel, dim3(grid), dim3(256), 0, st, *cam, sc->ws, b, d_out);
   }
   HIP_TRY(hipGetLastError());
-  return RT_OK;
+  return post_summary(sc, st);
 }
 
-int launch_render(const rt_scene* scene, const rt_camera* cam, const rt_options* opt, uint32_t part, uint32_t n_parts, int packed,
-                  double* d_out, hipStream_t stream, rt_stats* stats) {
+int launch_render_once(const rt_scene* scene, const rt_camera* cam, const rt_options* opt, uint32_t part, uint32_t n_parts, int packed,
+                       double* d_out, hipStream_t stream, rt_stats* stats) {
   int rc = check_render_args(scene, cam, opt);
   if (rc) return rc;
   if (!d_out) return fail(RT_ERR_INVALID_ARGUMENT, "output buffer is NULL");
@@ -840,6 +886,18 @@ int launch_render(const rt_scene* scene, const rt_camera* cam, const rt_options*
     if (ovf) return fail(RT_ERR_OVERFLOW, "a per-ray bounded list (BVH stack or CSG hit list) overflowed on the device");
   }
   return RT_OK;
+}
+
+// A statistics launch of the streamed pipeline must count every ray: the work of samples handed to the fallback kernel is
+// not counted, so the frame is rendered again with twice the node records per sample until none is.
+int launch_render(const rt_scene* scene, const rt_camera* cam, const rt_options* opt, uint32_t part, uint32_t n_parts, int packed,
+                  double* d_out, hipStream_t stream, rt_stats* stats) {
+  for (;;) {
+    int rc = launch_render_once(scene, cam, opt, part, n_parts, packed, d_out, stream, stats);
+    if (rc || !stats || stats->fallback_flags == 0 || scene->nodes_per_sample >= RT_STREAM_RATIO_MAX) return rc;
+    scene->summary_pending = false;  // the stream is idle here; the same count must not double the ratio again
+    scene->nodes_per_sample *= 2;
+  }
 }
 
 }  // namespace

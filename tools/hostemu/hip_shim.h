@@ -62,6 +62,8 @@ static inline hipError_t hipGetDeviceCount(int* n) { *n = 1; return hipSuccess; 
 static inline hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
 static inline hipError_t hipMalloc(void** p, size_t n) { *p = std::malloc(n); return hipSuccess; }
 static inline hipError_t hipFree(void* p) { std::free(p); return hipSuccess; }
+static inline hipError_t hipHostMalloc(void** p, size_t n) { *p = std::malloc(n); return hipSuccess; }
+static inline hipError_t hipHostFree(void* p) { std::free(p); return hipSuccess; }
 static inline hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { std::memcpy(d, s, n); return hipSuccess; }
 static inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t) { std::memcpy(d, s, n); return hipSuccess; }
 static inline hipError_t hipMemset(void* d, int v, size_t n) { std::memset(d, v, n); return hipSuccess; }
@@ -72,6 +74,7 @@ static inline hipError_t hipEventCreate(hipEvent_t* e) { *e = new hipEventRec{0.
 static inline hipError_t hipEventDestroy(hipEvent_t e) { delete e; return hipSuccess; }
 static inline hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return hipSuccess; }
 static inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
+static inline hipError_t hipEventQuery(hipEvent_t) { return hipSuccess; }
 static inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t, hipEvent_t) { *ms = 0.f; return hipSuccess; }
 
 template <class K, class... A>
