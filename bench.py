@@ -115,7 +115,7 @@ def main():
     flat = rs.builder.flatten()
     t_prep = time.perf_counter() - t0
     cam, opt = rs.camera, rs.options()
-    opt.pipeline = int(os.environ.get("RT_PIPELINE", "0"))  # development: 1 = the single-kernel core
+    opt.pipeline = int(os.environ.get("RT_PIPELINE", "0"))  # development: 1 = the single-kernel core (no per-kernel times)
     scene = R.DeviceScene(flat)  # upload: outside the timed region (inputs resident in HBM)
     stream = torch.cuda.current_stream().cuda_stream
 
@@ -128,26 +128,35 @@ def main():
         out = torch.empty((h, w, 3), dtype=torch.float64, device="cuda") if rank == 0 else None
         bufs = [torch.empty_like(local) for _ in range(world)] if rank == 0 else None
 
-    k0, k1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    kernel_ms = []
+    import ctypes as C
+
+    def clone_options(o, **kw):
+        c = type(o)()
+        C.memmove(C.byref(c), C.byref(o), C.sizeof(o))
+        for k, v in kw.items():
+            setattr(c, k, v)
+        return c
+
+    def launch(o, stats):
+        if world == 1:
+            return scene.render_device(cam, o, out.data_ptr(), stream, want_stats=stats)
+        return scene.render_tiles(cam, o, rank, world, local.data_ptr(), stream, want_stats=stats)
+
+    # rt_options.timing = 1: the production kernels, with a HIP event before and after every launch on the render's
+    # stream (inside librtcore); each timed step hands back the GPU time of every kernel class of that step.
+    topt = clone_options(opt, timing=1)
+    per_step = []
 
     def step(record=False):
         if record:
-            k0.record()
-        if world == 1:
-            scene.render_device(cam, opt, out.data_ptr(), stream)
+            per_step.append(launch(topt, True))
         else:
-            scene.render_tiles(cam, opt, rank, world, local.data_ptr(), stream)
-        if record:
-            k1.record()
+            launch(opt, False)
         if world > 1:
             dist.gather(local, gather_list=bufs, dst=0)
             if rank == 0:
                 g = torch.stack(bufs, 0)
                 R.assemble_tiles(w, h, world, n_max, g.data_ptr(), out.data_ptr(), stream)
-        if record:
-            k1.synchronize()
-            kernel_ms.append(k0.elapsed_time(k1))
 
     def barrier():
         if world > 1:
@@ -156,21 +165,12 @@ def main():
 
     # Untimed statistics launches (same rays, same pixels):
     #  * reference-order mode (rt_options.reference_order = 1): the BVH is visited exactly as ObjectGroup::intersect_iter
-    #    does, so its node/triangle/primitive counts are the reference's ALGORITHMIC work -> roofline bytes;
-    #    its image is the full-size cross-check of the production traversal.
-    #  * production mode: the work the shipped kernel actually does, and its SIMD utilisation.
-    import ctypes as C
-    ropt = type(opt)()
-    C.memmove(C.byref(ropt), C.byref(opt), C.sizeof(opt))
-    ropt.reference_order = 1
+    #    does: its image is the full-size cross-check of the production pipeline, its counts the reference's own work.
+    #  * production mode with counters: the units each production kernel processes -> algorithmic bytes per launch.
     target = out if world == 1 else local
-    def launch(o, stats):
-        if world == 1:
-            return scene.render_device(cam, o, out.data_ptr(), stream, want_stats=stats)
-        return scene.render_tiles(cam, o, rank, world, local.data_ptr(), stream, want_stats=stats)
-    st = launch(ropt, True)
+    st_ref = launch(clone_options(opt, reference_order=1), True)
     ref_img = target.clone()
-    st_fast = launch(opt, True)
+    st = launch(opt, True)
     xdiff = float((target - ref_img).abs().max().item())
     del ref_img
     for _ in range(args.warmup):
@@ -182,11 +182,17 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
 
+    def mean(key):
+        return sum(p[key] for p in per_step) / len(per_step)
+
     n_pix_rank = w * h if world == 1 else D.tile_count(w, h, rank, world) * 64
-    keys = ["rays_primary", "rays_shadow", "rays_reflect", "rays_refract", "node_visits", "tri_tests", "prim_tests", "hits", "hit_bytes"]
-    extra = [elapsed, sum(kernel_ms) / len(kernel_ms), float(algorithmic_bytes(st, n_pix_rank)),
-             float(algorithmic_bytes(st_fast, n_pix_rank)), float(st_fast["lane_steps"]), float(st_fast["wave_steps"]), xdiff]
-    vec = torch.tensor([float(st[k]) for k in keys] + extra, dtype=torch.float64, device="cuda")
+    keys = ["rays_primary", "rays_shadow", "rays_reflect", "rays_refract", "node_visits", "tri_tests", "prim_tests", "hits", "hit_bytes",
+            "shadow_node_visits", "shadow_tri_tests", "shadow_prim_tests"]
+    tkeys = ["ms_kernel", "ms_trace_closest", "ms_retrace", "ms_shade", "ms_trace_shadow", "ms_combine", "ms_other",
+             "launches_trace_closest", "launches_trace_shadow"]
+    extra = [elapsed, float(algorithmic_bytes(st_ref, n_pix_rank)), float(st["lane_steps"]), float(st["wave_steps"]), xdiff,
+             float(st["fallback_flags"])]
+    vec = torch.tensor([float(st[k]) for k in keys] + [mean(k) for k in tkeys] + extra, dtype=torch.float64, device="cuda")
     if world > 1:
         allv = [torch.empty_like(vec) for _ in range(world)]
         dist.all_gather(allv, vec)
@@ -195,14 +201,23 @@ def main():
         allv = vec.cpu().unsqueeze(0)
     if rank == 0:
         tot = {k: int(allv[:, i].sum().item()) for i, k in enumerate(keys)}
-        t_max = float(allv[:, len(keys)].max())
+        r0 = {k: float(allv[0, i]) for i, k in enumerate(keys)}                       # rank 0's own units
+        tm = {k: float(allv[0, len(keys) + i]) for i, k in enumerate(tkeys)}           # rank 0's kernel times per step
+        ex = len(keys) + len(tkeys)
+        t_max = float(allv[:, ex].max())
         rays = unique_rays(tot)
         value = rays * args.steps / t_max / 1e6
-        # roofline of the dominant kernel (render_tiles_kernel) on rank 0
-        k_ms = float(allv[0, len(keys) + 1])
-        k_bytes_ref = float(allv[0, len(keys) + 2])   # reference-order counts
-        k_bytes = float(allv[0, len(keys) + 3])       # this launch's own counts
-        achieved = k_bytes / (k_ms * 1e-3) / 1e9
+        # Roofline of the dominant kernel on rank 0: the trace kernel class with the most GPU time per step.
+        shadow_bytes = 52 * r0["shadow_node_visits"] + 72 * r0["shadow_tri_tests"] + 113 * r0["shadow_prim_tests"]
+        closest_bytes = (52 * (r0["node_visits"] - r0["shadow_node_visits"]) + 72 * (r0["tri_tests"] - r0["shadow_tri_tests"]) +
+                         113 * (r0["prim_tests"] - r0["shadow_prim_tests"]))
+        if tm["ms_trace_shadow"] >= tm["ms_trace_closest"]:
+            kname, k_ms, k_launches, k_bytes = "stream::trace_shadow_kernel<false>", tm["ms_trace_shadow"], tm["launches_trace_shadow"], shadow_bytes
+        else:
+            kname, k_ms, k_launches, k_bytes = "stream::trace_closest_kernel<true, false>", tm["ms_trace_closest"], tm["launches_trace_closest"], closest_bytes
+        k_launches = max(1.0, k_launches)
+        achieved = k_bytes / max(1e-9, k_ms * 1e-3) / 1e9  # (bytes per launch) / (duration per launch)
+        frame_bytes = float(algorithmic_bytes(r0, n_pix_rank))
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
@@ -218,21 +233,25 @@ def main():
                        "partition": "single GPU, whole frame" if world == 1 else f"8x8 tiles cyclic over {world} GPUs + gather to rank 0",
                        "rays_per_frame": rays, "primary": tot["rays_primary"], "shadow": tot["rays_shadow"],
                        "reflect": tot["rays_reflect"], "refract": tot["rays_refract"],
-                       "host_scene_prep_s": round(t_prep, 2)},
+                       "pipeline": "single kernel" if opt.pipeline else "streamed", "host_scene_prep_s": round(t_prep, 2)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "render_tiles_kernel<false, false>", "kernel_ms": k_ms, "algorithmic_bytes_per_launch": k_bytes,
-                         "algorithmic_bytes_reference_order": k_bytes_ref,
-                         "achieved_reference_order_equivalent": k_bytes_ref / (k_ms * 1e-3) / 1e9,
-                         "simd_utilisation": float(allv[:, len(keys) + 4].sum() / max(1.0, 64.0 * float(allv[:, len(keys) + 5].sum()))),
+                         "kernel": kname, "kernel_ms": k_ms / k_launches, "launches_per_step": k_launches,
+                         "algorithmic_bytes_per_launch": k_bytes / k_launches,
+                         "whole_frame": {"ms_gpu": tm["ms_kernel"], "algorithmic_bytes": frame_bytes,
+                                         "achieved": frame_bytes / max(1e-9, tm["ms_kernel"] * 1e-3) / 1e9,
+                                         "algorithmic_bytes_reference_order": float(allv[0, ex + 1]),
+                                         "ms_by_kernel_class": {k[3:]: tm[k] for k in tkeys if k.startswith("ms_") and k != "ms_kernel"}},
+                         "simd_utilisation": float(allv[:, ex + 2].sum() / max(1.0, 64.0 * float(allv[:, ex + 3].sum()))),
                          "note": "algorithmic bytes = SURVEY.md §8d per-unit constants (52 B per box test, 72 B per triangle "
-                                 "test, 113 B per analytic-primitive test, per-hit shading bytes, 24 B per pixel) x the units "
-                                 "THIS launch processes (counted by an identical statistics launch); the same constants x the "
-                                 "counts of the reference's own visiting order (reference-order mode, more box tests for the "
-                                 "same pixels) are given as *_reference_order.  The scene working set (~40 MB) is served from "
-                                 "L2 / Infinity Cache, so real HBM traffic (`traffic`, PMC) is far below either figure"},
-            "parity": {"max_abs_diff_vs_reference_order_render": float(allv[:, len(keys) + 6].max()),
-                       "note": "full-size cross-check: production traversal vs reference-order traversal, f64 pixels"},
+                                 "test, 113 B per analytic-primitive test; whole frame: + per-hit shading bytes + 24 B per pixel) x the "
+                                 "units the kernel processes (counted by an identical statistics launch); kernel_ms = mean HIP-event "
+                                 "duration of one launch of that kernel inside the timed steps, on the render's stream.  The scene's "
+                                 "working set (~30 MB) is served from L2 / Infinity Cache, so real HBM traffic (`traffic`, PMC) is "
+                                 "far below the algorithmic figure"},
+            "parity": {"max_abs_diff_vs_reference_order_render": float(allv[:, ex + 4].max()),
+                       "fallback_flags": int(allv[:, ex + 5].sum()),
+                       "note": "full-size cross-check: production pipeline vs reference-order traversal, f64 pixels"},
         }
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(flat, cam, opt, args.cpu_budget)

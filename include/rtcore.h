@@ -169,6 +169,9 @@ typedef struct rt_options {
                                 RT_PIPELINE_SINGLE_KERNEL (1): one kernel holds a pixel's whole recursion (same pixels, bit
                                 for bit; kept for comparison and as the overflow fallback of the streamed pipeline).
                                 Ignored when reference_order = 1 */
+  uint32_t timing;           /* with stats != NULL and the streamed pipeline: launch the production kernels (no counters; the
+                                counter fields of rt_stats stay 0) with a HIP event before and after every launch, and report
+                                the time per kernel class in rt_stats.ms_* */
 } rt_options;
 #define RT_PIPELINE_STREAM 0u
 #define RT_PIPELINE_SINGLE_KERNEL 1u
@@ -192,9 +195,14 @@ typedef struct rt_stats {
                               end, summed over wavefronts; there clocks_traversal = wavefront clocks in the node loop and
                               clocks_machine = wavefront clocks in leaves (the rest: fetching rays, setting them up, storing
                               results, and the drain after the queue is dry) */
+  uint64_t shadow_node_visits, shadow_tri_tests, shadow_prim_tests; /* streamed pipeline: the part of node_visits / tri_tests /
+                              prim_tests done by trace_shadow_kernel */
+  uint64_t launches_trace_closest, launches_trace_shadow; /* rt_options.timing: launches behind the ms_* sums below */
   uint64_t fallback_flags; /* streamed pipeline: times a ray or hit found its batch's queues full; the samples concerned were
                               re-rendered by the single-kernel state machine (same pixels, slower).  0 in a well-sized batch */
   double ms_upload, ms_kernel, ms_download;
+  double ms_trace_closest, ms_retrace, ms_shade, ms_trace_shadow, ms_combine, ms_other; /* rt_options.timing: GPU time of the
+                              streamed pipeline's launches by kernel class, HIP events on the render's stream, summed over the frame */
 } rt_stats;
 
 /* ---- library ------------------------------------------------------------------------------ */

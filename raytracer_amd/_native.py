@@ -55,7 +55,7 @@ class rt_camera(C.Structure):
 
 class rt_options(C.Structure):
     _fields_ = [("n_offsets", C.c_uint32), ("offsets", C.c_double * 5), ("max_depth", C.c_uint32),
-                ("shadow_intensity", C.c_uint32), ("reference_order", C.c_uint32), ("pipeline", C.c_uint32)]
+                ("shadow_intensity", C.c_uint32), ("reference_order", C.c_uint32), ("pipeline", C.c_uint32), ("timing", C.c_uint32)]
 
 
 class rt_stats(C.Structure):
@@ -63,8 +63,8 @@ class rt_stats(C.Structure):
                 ("rays_refract", C.c_uint64), ("node_visits", C.c_uint64), ("tri_tests", C.c_uint64),
                 ("prim_tests", C.c_uint64), ("hits", C.c_uint64), ("hit_bytes", C.c_uint64), ("overflow_pixels", C.c_uint64),
                 ("wave_steps", C.c_uint64), ("lane_steps", C.c_uint64), ("rays_retraced", C.c_uint64), ("clocks_traversal", C.c_uint64),
-                ("clocks_machine", C.c_uint64), ("clocks_trace_total", C.c_uint64), ("fallback_flags", C.c_uint64), ("ms_upload", C.c_double),
-                ("ms_kernel", C.c_double), ("ms_download", C.c_double)]
+                ("clocks_machine", C.c_uint64), ("clocks_trace_total", C.c_uint64), ("shadow_node_visits", C.c_uint64), ("shadow_tri_tests", C.c_uint64), ("shadow_prim_tests", C.c_uint64), ("launches_trace_closest", C.c_uint64), ("launches_trace_shadow", C.c_uint64), ("fallback_flags", C.c_uint64), ("ms_upload", C.c_double),
+                ("ms_kernel", C.c_double), ("ms_download", C.c_double), ("ms_trace_closest", C.c_double), ("ms_retrace", C.c_double), ("ms_shade", C.c_double), ("ms_trace_shadow", C.c_double), ("ms_combine", C.c_double), ("ms_other", C.c_double)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}

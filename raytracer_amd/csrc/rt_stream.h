@@ -560,6 +560,7 @@ __global__ __launch_bounds__(64, RT_TRACE_WAVES) void trace_shadow_kernel(DevSce
     }
   }
   if (STATS && (threadIdx.x & 63u) == 0) cnt.cyc_total += (uint32_t)(((unsigned long long)clock64() - clk0) >> 6);
+  if (STATS) flush_shadow_counters(cnt, stats);
   flush_counters<STATS>(cnt, stats, overflow_flag);
 }
 

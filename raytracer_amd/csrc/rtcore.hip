@@ -17,7 +17,8 @@
 // ---------------------------------------------------------------------------------------------
 // kernels
 // ---------------------------------------------------------------------------------------------
-#define RT_N_COUNTERS 17
+#define RT_N_COUNTERS 20
+#define RT_COUNTER_SHADOW 17  // streamed pipeline: box / triangle / primitive tests done by trace_shadow_kernel (3 slots)
 #define RT_COUNTER_FALLBACK 15  // streamed pipeline: flag events of samples handed to the fallback kernel
 #ifndef RT_WAVES_PER_EU
 #define RT_WAVES_PER_EU 2  // waves per SIMD the register allocator must leave room for (256 VGPRs: no spills; measured best)
@@ -34,6 +35,16 @@ __device__ __forceinline__ void flush_counters(const Counters& c, unsigned long 
     unsigned long long x = v[k];
     for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
     if ((threadIdx.x & 63) == 0 && x) atomicAdd(&stats[k == 15 ? 16 : k], x);
+  }
+}
+
+// trace_shadow_kernel's share of the traversal counters, kept apart for its roofline (bench.py).
+__device__ __forceinline__ void flush_shadow_counters(const Counters& c, unsigned long long* stats) {
+  uint32_t v[3] = {c.node_visits, c.tri_tests, c.prim_tests};
+  for (int k = 0; k < 3; k++) {
+    unsigned long long x = v[k];
+    for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
+    if ((threadIdx.x & 63) == 0 && x) atomicAdd(&stats[RT_COUNTER_SHADOW + k], x);
   }
 }
 
@@ -256,11 +267,16 @@ struct rt_scene {
   mutable uint32_t* h_summary = nullptr;  // pinned copy, valid once summary_event has completed
   mutable hipEvent_t summary_event = nullptr;
   mutable bool summary_pending = false;
+  // rt_options.timing: HIP events around every launch of the streamed pipeline, by kernel class
+  mutable bool timing_on = false;
+  mutable std::vector<hipEvent_t> event_pool;
+  mutable std::vector<int> timed_class;  // class of the i-th timed launch (events 2i, 2i+1 of the pool)
   ~rt_scene() {
     if (ws_base) (void)hipFree(ws_base);
     if (d_summary) (void)hipFree(d_summary);
     if (h_summary) (void)hipHostFree(h_summary);
     if (summary_event) (void)hipEventDestroy(summary_event);
+    for (hipEvent_t e : event_pool) (void)hipEventDestroy(e);
   }
 };
 
@@ -753,6 +769,31 @@ int post_summary(const rt_scene* sc, hipStream_t st) {
   return RT_OK;
 }
 
+enum { TC_TRACE_CLOSEST = 0, TC_RETRACE, TC_SHADE, TC_TRACE_SHADOW, TC_COMBINE, TC_OTHER, TC_COUNT };
+
+struct TimedLaunch {  // records an event before and after one launch when the scene is in timing mode
+  const rt_scene* sc;
+  hipStream_t st;
+  bool on;
+  TimedLaunch(const rt_scene* scene, hipStream_t stream, int cls) : sc(scene), st(stream), on(scene->timing_on) {
+    if (!on) return;
+    size_t i = sc->timed_class.size();
+    while (sc->event_pool.size() < 2 * i + 2) {
+      hipEvent_t e = nullptr;
+      if (hipEventCreate(&e) != hipSuccess) {
+        on = false;
+        return;
+      }
+      sc->event_pool.push_back(e);
+    }
+    sc->timed_class.push_back(cls);
+    (void)hipEventRecord(sc->event_pool[2 * i], st);
+  }
+  ~TimedLaunch() {
+    if (on) (void)hipEventRecord(sc->event_pool[2 * sc->timed_class.size() - 1], st);
+  }
+};
+
 // One batch through every level (see rt_stream.h).  CAMERA: level 0 is generated from the camera; otherwise it is the
 // batch's given rays (rt_trace_rays).
 template <bool CAMERA, bool STATS>
@@ -765,19 +806,39 @@ int run_stream_batch(const rt_scene* sc, const rt_camera& cam, const DevOptions&
   HIP_TRY(hipMemsetAsync(w.ctrl, 0, sizeof(stream::Ctrl), st));
   HIP_TRY(hipMemsetAsync(w.sample_flag, 0, b.n_samples, st));
   for (uint32_t level = 0; level <= dopt.max_depth; level++) {
-    hipLaunchKernelGGL((stream::trace_closest_kernel<CAMERA, STATS>), dim3(trace_grid), dim3(64), 0, st, sc->dev, cam, dopt, w, b, level,
-                       sc->d_stats, sc->d_overflow);
-    hipLaunchKernelGGL((stream::retrace_kernel<CAMERA, STATS>), dim3((uint32_t)sc->n_cus), dim3(64), 0, st, sc->dev, cam, dopt, w, b, level,
-                       sc->d_stats, sc->d_overflow);
-    hipLaunchKernelGGL((stream::shade_kernel<CAMERA, STATS>), dim3(level == 0 ? first_grid : wide_grid), dim3(256), 0, st, sc->dev, cam,
-                       dopt, w, b, level, sc->d_stats, sc->d_overflow);
-    hipLaunchKernelGGL(stream::close_level_kernel, dim3(1), dim3(64), 0, st, w, level);
+    {
+      TimedLaunch t(sc, st, TC_TRACE_CLOSEST);
+      hipLaunchKernelGGL((stream::trace_closest_kernel<CAMERA, STATS>), dim3(trace_grid), dim3(64), 0, st, sc->dev, cam, dopt, w, b,
+                         level, sc->d_stats, sc->d_overflow);
+    }
+    {
+      TimedLaunch t(sc, st, TC_RETRACE);
+      hipLaunchKernelGGL((stream::retrace_kernel<CAMERA, STATS>), dim3((uint32_t)sc->n_cus * 4u), dim3(64), 0, st, sc->dev, cam, dopt, w,
+                         b, level, sc->d_stats, sc->d_overflow);
+    }
+    {
+      TimedLaunch t(sc, st, TC_SHADE);
+      hipLaunchKernelGGL((stream::shade_kernel<CAMERA, STATS>), dim3(level == 0 ? first_grid : wide_grid), dim3(256), 0, st, sc->dev,
+                         cam, dopt, w, b, level, sc->d_stats, sc->d_overflow);
+    }
+    {
+      TimedLaunch t(sc, st, TC_OTHER);
+      hipLaunchKernelGGL(stream::close_level_kernel, dim3(1), dim3(64), 0, st, w, level);
+    }
   }
-  hipLaunchKernelGGL((stream::trace_shadow_kernel<STATS>), dim3(trace_grid), dim3(64), 0, st, sc->dev, w, sc->d_stats, sc->d_overflow);
-  for (uint32_t level = dopt.max_depth + 1; level-- > 0;)
+  {
+    TimedLaunch t(sc, st, TC_TRACE_SHADOW);
+    hipLaunchKernelGGL((stream::trace_shadow_kernel<STATS>), dim3(trace_grid), dim3(64), 0, st, sc->dev, w, sc->d_stats, sc->d_overflow);
+  }
+  for (uint32_t level = dopt.max_depth + 1; level-- > 0;) {
+    TimedLaunch t(sc, st, TC_COMBINE);
     hipLaunchKernelGGL(stream::combine_kernel, dim3(wide_grid), dim3(256), 0, st, sc->dev, dopt, w, level);
-  hipLaunchKernelGGL((stream::fallback_kernel<CAMERA>), dim3((uint32_t)sc->n_cus * 8u), dim3(64), 0, st, sc->dev, cam, dopt, w, b,
-                     STATS ? sc->d_stats : nullptr, sc->d_summary, sc->d_overflow);
+  }
+  {
+    TimedLaunch t(sc, st, TC_OTHER);
+    hipLaunchKernelGGL((stream::fallback_kernel<CAMERA>), dim3((uint32_t)sc->n_cus * 8u), dim3(64), 0, st, sc->dev, cam, dopt, w, b,
+                       STATS ? sc->d_stats : nullptr, sc->d_summary, sc->d_overflow);
+  }
   HIP_TRY(hipGetLastError());
   return RT_OK;
 }
@@ -810,6 +871,7 @@ int launch_stream_render(const rt_scene* sc, const rt_camera* cam, const DevOpti
     rc = run_stream_batch<true, STATS>(sc, *cam, dopt, b, st);
     if (rc) return rc;
     uint32_t grid = std::max(1u, std::min((uint32_t)sc->n_cus * 8u, (b.n_tiles * 64u + 255u) / 256u));
+    TimedLaunch t(sc, st, TC_OTHER);
     hipLaunchKernelGGL(stream::resolve_kernel, dim3(grid), dim3(256), 0, st, *cam, sc->ws, b, d_out);
   }
   HIP_TRY(hipGetLastError());
@@ -846,8 +908,12 @@ int launch_render_once(const rt_scene* scene, const rt_camera* cam, const rt_opt
       if (stats) RT_LAUNCH_TILES(true, false);
       else RT_LAUNCH_TILES(false, false);
     } else {
-      rc = stats ? launch_stream_render<true>(scene, cam, dopt, part, n_parts, tiles_x, n_owned, packed, d_out, stream)
-                 : launch_stream_render<false>(scene, cam, dopt, part, n_parts, tiles_x, n_owned, packed, d_out, stream);
+      // rt_options.timing: the production kernels (no counters) with events around every launch
+      scene->timing_on = stats && opt->timing;
+      scene->timed_class.clear();
+      rc = (stats && !opt->timing) ? launch_stream_render<true>(scene, cam, dopt, part, n_parts, tiles_x, n_owned, packed, d_out, stream)
+                                   : launch_stream_render<false>(scene, cam, dopt, part, n_parts, tiles_x, n_owned, packed, d_out, stream);
+      scene->timing_on = false;
       if (rc) return rc;
     }
 #undef RT_LAUNCH_TILES
@@ -882,6 +948,20 @@ int launch_render_once(const rt_scene* scene, const rt_camera* cam, const rt_opt
     stats->clocks_machine = h[14] * 64;
     stats->fallback_flags = h[15];
     stats->clocks_trace_total = h[16] * 64;
+    stats->shadow_node_visits = h[RT_COUNTER_SHADOW];
+    stats->shadow_tri_tests = h[RT_COUNTER_SHADOW + 1];
+    stats->shadow_prim_tests = h[RT_COUNTER_SHADOW + 2];
+    double* ms_class[TC_COUNT] = {&stats->ms_trace_closest, &stats->ms_retrace, &stats->ms_shade, &stats->ms_trace_shadow,
+                                  &stats->ms_combine,       &stats->ms_other};
+    for (size_t i = 0; i < scene->timed_class.size(); i++) {
+      float t = 0.f;
+      if (hipEventElapsedTime(&t, scene->event_pool[2 * i], scene->event_pool[2 * i + 1]) != hipSuccess) continue;
+      int c = scene->timed_class[i];
+      *ms_class[c] += t;
+      if (c == TC_TRACE_CLOSEST) stats->launches_trace_closest++;
+      if (c == TC_TRACE_SHADOW) stats->launches_trace_shadow++;
+    }
+    scene->timed_class.clear();
     stats->ms_kernel = ms;
     if (ovf) return fail(RT_ERR_OVERFLOW, "a per-ray bounded list (BVH stack or CSG hit list) overflowed on the device");
   }

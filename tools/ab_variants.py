@@ -11,4 +11,4 @@ for lib in sys.argv[1:]:
         if not line:
             print(lib, wl, "FAILED", r.stderr[-500:], flush=True); continue
         j = json.loads(line[-1])
-        print(f"{os.path.basename(lib):28s} {wl:22s} {j['ms_per_step']:10.2f} ms  {j['value']:9.1f} Mrays/s  frac {j['roofline']['frac']:.4f}  simd {j['roofline']['simd_utilisation']:.3f}  xdiff {j['parity']['max_abs_diff_vs_reference_order_render']:.1e}", flush=True)
+        print(f"{os.path.basename(lib):28s} {wl:22s} {j['ms_per_step']:10.2f} ms  {j['value']:9.1f} Mrays/s  frac {j["roofline"]["frac"]:.4f}  simd {j['roofline']['simd_utilisation']:.3f}  xdiff {j['parity']['max_abs_diff_vs_reference_order_render']:.1e}", flush=True)
