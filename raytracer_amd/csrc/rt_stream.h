@@ -106,24 +106,54 @@ __device__ __forceinline__ uint32_t wave_take(uint32_t* counter, bool want) {
 // with its own 4 MB L2, so the items (rays in queue order = image order) are cut into chunks of RT_XCD_CHUNK and chunk c
 // belongs to XCD c % 8: the rays in flight on one XCD then cover a compact patch of the image and walk the same BVH
 // subtrees, which its L2 can hold.  Each XCD has its own counter over its share; a wavefront whose XCD's share is used
-// up takes from the next XCD's (`victim`, wave-uniform, only ever advances).  Returns RT_NONE when nothing is left.
+// up takes from the next XCD's (`victim`, only ever advances).
+// A wavefront does not go to the counter for every refill: returning atomics on one address are served one after the
+// other (~90 ns each), which at 64 rays per atomic bounded the trace kernels at ~0.7 G rays/s per counter.  It takes
+// RT_XCD_GRAB items at a time and hands them to its lanes from that private range.  All cursor fields are wave-uniform.
 #ifndef RT_XCD_CHUNK
 #define RT_XCD_CHUNK 65536u
 #endif
-__device__ __forceinline__ uint32_t xcd_take(uint32_t* counters, uint32_t n_items, uint32_t xcd, uint32_t& victim, bool want) {
+#ifndef RT_XCD_GRAB
+#define RT_XCD_GRAB 1024u  // divides RT_XCD_CHUNK
+#endif
+struct XcdCursor {
+  uint32_t xcd, victim, next, end;  // [next, end): items of XCD (xcd + victim) & 7's share this wavefront has taken
+  uint32_t grab;                    // items per atomic: 64 .. RT_XCD_GRAB, so that every wavefront still gets several turns
+};
+__device__ __forceinline__ XcdCursor xcd_cursor(uint32_t n_items) {
+  uint32_t grab = 64u;
+  while (grab < RT_XCD_GRAB && (unsigned long long)grab * gridDim.x * 8u < n_items) grab <<= 1;
+  return XcdCursor{blockIdx.x & 7u, 0u, 0u, 0u, grab};
+}
+
+// Every lane with `want` gets a distinct item id < n_items, or RT_NONE when nothing is left.
+__device__ __forceinline__ uint32_t xcd_take(uint32_t* counters, uint32_t n_items, XcdCursor& c, bool want) {
   uint32_t id = RT_NONE;
-  while (victim < 8u) {
+  while (c.victim < 8u) {
     bool w = want && id == RT_NONE;
-    if (__builtin_amdgcn_ballot_w64(w) == 0ull) break;
-    uint32_t xx = (xcd + victim) & 7u;
-    uint32_t q = wave_take(&counters[xx], w);
+    unsigned long long m = __builtin_amdgcn_ballot_w64(w);
+    if (m == 0ull) break;
+    uint32_t xx = (c.xcd + c.victim) & 7u;
+    if (c.next == c.end) {  // take the next c.grab items of that XCD's share
+      uint32_t q = 0;
+      if (w && rank_in(m) == 0) q = atomicAdd(&counters[xx], c.grab);
+      q = __builtin_amdgcn_readfirstlane(__shfl(q, __ffsll((long long)m) - 1, 64));
+      c.next = q;
+      c.end = q + c.grab;
+    }
+    uint32_t avail = c.end - c.next, r = rank_in(m);
     bool failed = false;
-    if (w) {
+    if (w && r < avail) {
+      uint32_t q = c.next + r;
       unsigned long long g = ((unsigned long long)(q / RT_XCD_CHUNK) * 8u + xx) * RT_XCD_CHUNK + q % RT_XCD_CHUNK;
       if (g < n_items) id = (uint32_t)g;
       else failed = true;
     }
-    if (__builtin_amdgcn_ballot_w64(failed) != 0ull) victim++;  // ids only grow: that share is used up
+    c.next += min(avail, (uint32_t)__builtin_popcountll(m));
+    if (__builtin_amdgcn_ballot_w64(failed) != 0ull) {  // ids only grow: that share is used up
+      c.victim++;
+      c.next = c.end = 0;
+    }
   }
   return id;
 }
@@ -241,8 +271,11 @@ __device__ __forceinline__ void flag_sample(const Ws& w, uint32_t root) {
 #define RT_REFILL_BELOW 16
 #endif
 
+#ifndef RT_CLOSEST_WAVES
+#define RT_CLOSEST_WAVES RT_TRACE_WAVES
+#endif
 template <bool CAMERA, bool STATS>
-__global__ __launch_bounds__(64, RT_TRACE_WAVES) void trace_closest_kernel(DevScene s, rt_camera cam, DevOptions opt, Ws w, Batch b,
+__global__ __launch_bounds__(64, RT_CLOSEST_WAVES) void trace_closest_kernel(DevScene s, rt_camera cam, DevOptions opt, Ws w, Batch b,
                                                                           uint32_t level, unsigned long long* stats,
                                                                           uint32_t* overflow_flag) {
   __shared__ uint2 lds_stack[RT_LDS_STACK * 64];
@@ -260,12 +293,12 @@ __global__ __launch_bounds__(64, RT_TRACE_WAVES) void trace_closest_kernel(DevSc
   uint32_t my = RT_NONE;  // the ray this lane is working on
   double ht = 0., hu = 0., hv = 0.;  // the hit, kept across the container walk
   bool exhausted = false;
-  uint32_t victim = 0;
+  XcdCursor cursor = xcd_cursor(n_rays);
   for (;;) {
     // ---- idle lanes take the next rays of the level ----
     bool want = my == RT_NONE && !exhausted;
     if (__builtin_amdgcn_ballot_w64(want) != 0ull) {
-      uint32_t id = xcd_take(w.ctrl->fetch[level], n_rays, blockIdx.x & 7u, victim, want);
+      uint32_t id = xcd_take(w.ctrl->fetch[level], n_rays, cursor, want);
       if (want) {
         if (id != RT_NONE) {
           d3 o, d;
@@ -530,11 +563,11 @@ __global__ __launch_bounds__(64, RT_TRACE_WAVES) void trace_shadow_kernel(DevSce
   T.a = 0.;
   uint32_t my = RT_NONE, light = 0;  // the node this lane is working on, and the light of its current ray
   bool exhausted = false;
-  uint32_t victim = 0;
+  XcdCursor cursor = xcd_cursor(n_items);
   for (;;) {
     bool want = my == RT_NONE && !exhausted;
     if (__builtin_amdgcn_ballot_w64(want) != 0ull) {
-      uint32_t id = xcd_take(w.ctrl->shadow_fetch, n_items, blockIdx.x & 7u, victim, want);
+      uint32_t id = xcd_take(w.ctrl->shadow_fetch, n_items, cursor, want);
       if (want) {
         if (id != RT_NONE) {
           light = id / n_nodes;

@@ -799,7 +799,7 @@ struct TimedLaunch {  // records an event before and after one launch when the s
 template <bool CAMERA, bool STATS>
 int run_stream_batch(const rt_scene* sc, const rt_camera& cam, const DevOptions& dopt, const stream::Batch& b, hipStream_t st) {
   const stream::Ws& w = sc->ws;
-  const uint32_t trace_grid = (uint32_t)sc->n_cus * 4u * RT_TRACE_WAVES;
+  const uint32_t trace_grid = (uint32_t)sc->n_cus * 4u * RT_TRACE_WAVES, closest_grid = (uint32_t)sc->n_cus * 4u * RT_CLOSEST_WAVES;
   const uint32_t wide_grid = (uint32_t)sc->n_cus * 8u;
   uint32_t need = (b.n_samples + 255u) / 256u;
   const uint32_t first_grid = std::max(1u, std::min(wide_grid, need));
@@ -808,7 +808,7 @@ int run_stream_batch(const rt_scene* sc, const rt_camera& cam, const DevOptions&
   for (uint32_t level = 0; level <= dopt.max_depth; level++) {
     {
       TimedLaunch t(sc, st, TC_TRACE_CLOSEST);
-      hipLaunchKernelGGL((stream::trace_closest_kernel<CAMERA, STATS>), dim3(trace_grid), dim3(64), 0, st, sc->dev, cam, dopt, w, b,
+      hipLaunchKernelGGL((stream::trace_closest_kernel<CAMERA, STATS>), dim3(closest_grid), dim3(64), 0, st, sc->dev, cam, dopt, w, b,
                          level, sc->d_stats, sc->d_overflow);
     }
     {

@@ -39,6 +39,7 @@ static inline unsigned long long __builtin_amdgcn_ballot_w64(bool b) { return b 
 static inline long long clock64() { return 0; }
 static inline int __ffsll(long long v) { return __builtin_ffsll(v); }
 template <class T> static inline T __shfl_down(T, int, int) { return T(0); }
+template <class T> static inline T __shfl(T v, int, int) { return v; }
 template <class T> static inline T atomicAdd(T* p, T v) { T o = *p; *p += v; return o; }
 static inline uint32_t atomicOr(uint32_t* p, uint32_t v) { uint32_t o = *p; *p |= v; return o; }
 
