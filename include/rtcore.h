@@ -197,6 +197,7 @@ typedef struct rt_stats {
                               results, and the drain after the queue is dry) */
   uint64_t shadow_node_visits, shadow_tri_tests, shadow_prim_tests; /* streamed pipeline: the part of node_visits / tri_tests /
                               prim_tests done by trace_shadow_kernel */
+  uint64_t shadow_wave_steps, shadow_lane_steps, shadow_clocks_node, shadow_clocks_leaf, shadow_clocks_total; /* likewise */
   uint64_t launches_trace_closest, launches_trace_shadow; /* rt_options.timing: launches behind the ms_* sums below */
   uint64_t fallback_flags; /* streamed pipeline: times a ray or hit found its batch's queues full; the samples concerned were
                               re-rendered by the single-kernel state machine (same pixels, slower).  0 in a well-sized batch */

@@ -272,7 +272,7 @@ __device__ __forceinline__ void flag_sample(const Ws& w, uint32_t root) {
 #endif
 
 #ifndef RT_CLOSEST_WAVES
-#define RT_CLOSEST_WAVES RT_TRACE_WAVES
+#define RT_CLOSEST_WAVES 3  // the closest-hit kernel also carries the container walk and CSG: 168 VGPRs, no spills in its loops (measured best)
 #endif
 template <bool CAMERA, bool STATS>
 __global__ __launch_bounds__(64, RT_CLOSEST_WAVES) void trace_closest_kernel(DevScene s, rt_camera cam, DevOptions opt, Ws w, Batch b,

@@ -17,8 +17,8 @@
 // ---------------------------------------------------------------------------------------------
 // kernels
 // ---------------------------------------------------------------------------------------------
-#define RT_N_COUNTERS 20
-#define RT_COUNTER_SHADOW 17  // streamed pipeline: box / triangle / primitive tests done by trace_shadow_kernel (3 slots)
+#define RT_N_COUNTERS 25
+#define RT_COUNTER_SHADOW 17  // streamed pipeline: trace_shadow_kernel's own box / triangle / primitive tests, wave / lane steps, node / leaf / total clocks (8 slots)
 #define RT_COUNTER_FALLBACK 15  // streamed pipeline: flag events of samples handed to the fallback kernel
 #ifndef RT_WAVES_PER_EU
 #define RT_WAVES_PER_EU 2  // waves per SIMD the register allocator must leave room for (256 VGPRs: no spills; measured best)
@@ -40,8 +40,8 @@ __device__ __forceinline__ void flush_counters(const Counters& c, unsigned long 
 
 // trace_shadow_kernel's share of the traversal counters, kept apart for its roofline (bench.py).
 __device__ __forceinline__ void flush_shadow_counters(const Counters& c, unsigned long long* stats) {
-  uint32_t v[3] = {c.node_visits, c.tri_tests, c.prim_tests};
-  for (int k = 0; k < 3; k++) {
+  uint32_t v[8] = {c.node_visits, c.tri_tests, c.prim_tests, c.wave_steps, c.lane_steps, c.cyc_trav, c.cyc_adv, c.cyc_total};
+  for (int k = 0; k < 8; k++) {
     unsigned long long x = v[k];
     for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
     if ((threadIdx.x & 63) == 0 && x) atomicAdd(&stats[RT_COUNTER_SHADOW + k], x);
@@ -951,6 +951,11 @@ int launch_render_once(const rt_scene* scene, const rt_camera* cam, const rt_opt
     stats->shadow_node_visits = h[RT_COUNTER_SHADOW];
     stats->shadow_tri_tests = h[RT_COUNTER_SHADOW + 1];
     stats->shadow_prim_tests = h[RT_COUNTER_SHADOW + 2];
+    stats->shadow_wave_steps = h[RT_COUNTER_SHADOW + 3];
+    stats->shadow_lane_steps = h[RT_COUNTER_SHADOW + 4];
+    stats->shadow_clocks_node = h[RT_COUNTER_SHADOW + 5] * 64;
+    stats->shadow_clocks_leaf = h[RT_COUNTER_SHADOW + 6] * 64;
+    stats->shadow_clocks_total = h[RT_COUNTER_SHADOW + 7] * 64;
     double* ms_class[TC_COUNT] = {&stats->ms_trace_closest, &stats->ms_retrace, &stats->ms_shade, &stats->ms_trace_shadow,
                                   &stats->ms_combine,       &stats->ms_other};
     for (size_t i = 0; i < scene->timed_class.size(); i++) {
