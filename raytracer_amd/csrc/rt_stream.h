@@ -34,7 +34,7 @@
 namespace stream {
 
 #define RT_RAY_STRIDE 8  // doubles per queued ray: origin, direction, (parent, root) as two u32, one spare
-#define RT_HIT_STRIDE 6  // doubles per hit record: primitive (u64 bits), t, u, v, n1, n2
+#define RT_HIT_FIELDS 5  // doubles per hit: t, u, v, n1, n2 (the primitive is kept apart: a miss writes and reads 4 bytes)
 #define RT_LEVELS (RT_MAX_DEPTH + 1)
 
 // Node tables are struct-of-arrays: field f of node i at [f * cap_nodes + i], so that a wavefront working on consecutive
@@ -59,7 +59,8 @@ struct Ctrl {  // device-resident control block of one batch; zeroed when the ba
 struct Ws {  // workspace of one batch (device pointers; owned by rt_scene)
   Ctrl* ctrl;
   double* rays[2];       // [cap_rays][RT_RAY_STRIDE]; level l reads rays[l & 1], writes rays[(l + 1) & 1]
-  double* hits;          // [max(n_samples, cap_rays)][RT_HIT_STRIDE] hit records of the level being processed
+  double* hit_f;         // [RT_HIT_FIELDS][cap_rays] t, u, v, n1, n2 of the hits of the level being processed
+  uint32_t* hit_prim[2]; // primitive hit by each ray (RT_NONE: miss): [0] level 0, [n_samples], kept for resolve; [1] deeper levels, [cap_rays]
   uint32_t* retrace;     // [max(n_samples, cap_rays)]
   double* node_f;        // [NF_COUNT][cap_nodes]
   uint32_t* node_u;      // [NU_COUNT][cap_nodes]
@@ -238,16 +239,17 @@ __device__ __forceinline__ void store_ray(double* __restrict__ q, uint32_t id, d
   r[6] = bitsd((uint64_t)parent | ((uint64_t)root << 32));
 }
 
-__device__ __forceinline__ void store_hit(double* __restrict__ hits, uint32_t id, uint32_t prim, double t, double u, double v, double n1,
-                                          double n2) {
-  double* h = hits + (size_t)id * RT_HIT_STRIDE;
-  h[0] = bitsd(prim);
+__device__ __forceinline__ void store_hit(const Ws& w, uint32_t level, uint32_t id, uint32_t prim, double t, double u, double v,
+                                          double n1, double n2) {
+  w.hit_prim[level ? 1 : 0][id] = prim;
   if (prim != RT_NONE) {
-    h[1] = t;
-    h[2] = u;
-    h[3] = v;
-    h[4] = n1;
-    h[5] = n2;
+    double* h = w.hit_f + id;
+    const size_t cap = w.cap_rays;
+    h[0] = t;
+    h[cap] = u;
+    h[2 * cap] = v;
+    h[3 * cap] = n1;
+    h[4 * cap] = n2;
   }
 }
 
@@ -314,7 +316,7 @@ __global__ __launch_bounds__(64, RT_CLOSEST_WAVES) void trace_closest_kernel(Dev
             my = id;
             fast::trav_start(T, o, d, fast::M_CLOSEST, INFINITY);
           } else {
-            store_hit(w.hits, id, RT_NONE, 0., 0., 0., 0., 0.);
+            store_hit(w, level, id, RT_NONE, 0., 0., 0., 0., 0.);
           }
         } else {
           exhausted = true;
@@ -332,7 +334,7 @@ __global__ __launch_bounds__(64, RT_CLOSEST_WAVES) void trace_closest_kernel(Dev
     if (my != RT_NONE && T.cur == RT_FREF_NONE) {
       if (T.mode == fast::M_CLOSEST) {
         if (T.p == RT_NONE) {  // miss
-          store_hit(w.hits, my, RT_NONE, 0., 0., 0., 0., 0.);
+          store_hit(w, level, my, RT_NONE, 0., 0., 0., 0., 0.);
           my = RT_NONE;
         } else if (T.t2 <= fast::near_limit(T.limit)) {  // coincident surfaces: settled by the retrace kernel
           uint32_t k = atomicAdd(&w.ctrl->n_retrace[level], 1u);
@@ -350,14 +352,14 @@ __global__ __launch_bounds__(64, RT_CLOSEST_WAVES) void trace_closest_kernel(Dev
             fast::trav_start(T, o, d, fast::M_CONTAINERS, 0.);
             T.h = hprim;
           } else {
-            store_hit(w.hits, my, T.p, T.limit, T.a, T.b, 1.0, 1.0);
+            store_hit(w, level, my, T.p, T.limit, T.a, T.b, 1.0, 1.0);
             my = RT_NONE;
           }
         }
       } else {  // the container walk is complete
         double n1, n2;
         fast::refractive_indices(s, T, T.h, n1, n2);
-        store_hit(w.hits, my, T.h, ht, hu, hv, n1, n2);
+        store_hit(w, level, my, T.h, ht, hu, hv, n1, n2);
         T.mode = fast::M_CLOSEST;
         my = RT_NONE;
       }
@@ -403,7 +405,7 @@ __global__ __launch_bounds__(64, 2) void retrace_kernel(DevScene s, rt_camera ca
         fast::refractive_indices(s, T, c.hit_prim, n1, n2);
       }
     }
-    store_hit(w.hits, id, c.hit_prim, c.limit, c.hu, c.hv, n1, n2);
+    store_hit(w, level, id, c.hit_prim, c.limit, c.hu, c.hv, n1, n2);
   }
   flush_counters<STATS>(cnt, stats, overflow_flag);
 }
@@ -425,17 +427,11 @@ __global__ __launch_bounds__(256) void shade_kernel(DevScene s, rt_camera cam, D
     uint32_t id = wbase + lane;
     bool valid = id < n_rays;
     uint32_t prim = RT_NONE;
-    if (valid) prim = (uint32_t)dbits(w.hits[(size_t)id * RT_HIT_STRIDE]);
+    if (valid) prim = w.hit_prim[level ? 1 : 0][id];
     bool hit = valid && prim != RT_NONE;
     d3 o = mk3(0., 0., 0.), d = mk3(0., 0., 1.);
     uint32_t parent = id, root = id;  // level 0: the sample
     if (valid && level != 0) load_ray(queue, id, o, d, parent, root);
-    if (valid && !hit && level == 0) {  // miss: black (integrator.rs:62-65)
-      double* c = w.sample_rgb + (size_t)parent * 3;
-      c[0] = 0.;
-      c[1] = 0.;
-      c[2] = 0.;
-    }
     uint32_t node = wave_take(&w.ctrl->n_nodes, hit);
     if (hit && node >= w.cap_nodes) {  // no room for this hit: the whole sample goes to the fallback
       flag_sample(w, root);
@@ -445,8 +441,9 @@ __global__ __launch_bounds__(256) void shade_kernel(DevScene s, rt_camera cam, D
     d3 child_o[2], child_d[2];
     if (hit) {
       if (level == 0) first_ray<CAMERA>(cam, opt, b, id, o, d);
-      const double* h = w.hits + (size_t)id * RT_HIT_STRIDE;
-      double t = h[1], u = h[2], v = h[3], n1 = h[4], n2 = h[5];
+      const double* h = w.hit_f + id;
+      const size_t hcap = w.cap_rays;
+      double t = h[0], u = h[hcap], v = h[2 * hcap], n1 = h[3 * hcap], n2 = h[4 * hcap];
       uint4 info = s.prim_info[prim];
       const double* mat = s.material + (size_t)info.y * RT_MAT_STRIDE;
       HitGeom g = hit_geom(s, info, o, d, t, u, v);
@@ -693,7 +690,12 @@ __global__ __launch_bounds__(256) void resolve_kernel(rt_camera cam, Ws w, Batch
     d3 color = mk3(0., 0., 0.);
     if (inside) {
       const double* src = w.sample_rgb + ((size_t)tl * b.n2 * 64u + p) * 3;
-      for (uint32_t k = 0; k < b.n2; k++, src += 64 * 3) color = add3(color, mk3(src[0], src[1], src[2]));
+      const uint32_t* hp = w.hit_prim[0] + ((size_t)tl * b.n2 * 64u + p);
+      for (uint32_t k = 0; k < b.n2; k++, src += 64 * 3, hp += 64) {
+        d3 c = mk3(0., 0., 0.);  // a sample whose ray hit nothing is black (integrator.rs:62-65); nothing was stored for it
+        if (*hp != RT_NONE) c = mk3(src[0], src[1], src[2]);
+        color = add3(color, c);
+      }
     }
     color = mk3(color.x / nn, color.y / nn, color.z / nn);  // renderer.rs:65
     if (b.packed) {

@@ -675,7 +675,9 @@ size_t carve_workspace(stream::Ws* w, char* base, uint64_t n, uint32_t ratio, ui
   size_t o_ctrl = take(sizeof(stream::Ctrl));
   size_t o_rays0 = take((size_t)cap_rays * RT_RAY_STRIDE * 8);
   size_t o_rays1 = take((size_t)cap_rays * RT_RAY_STRIDE * 8);
-  size_t o_hits = take((size_t)cap_rays * RT_HIT_STRIDE * 8);
+  size_t o_hits = take((size_t)cap_rays * RT_HIT_FIELDS * 8);
+  size_t o_hp0 = take((size_t)n * 4);
+  size_t o_hp1 = take((size_t)cap_rays * 4);
   size_t o_retrace = take((size_t)cap_rays * 4);
   size_t o_nf = take((size_t)cap_nodes * stream::NF_COUNT * 8);
   size_t o_nu = take((size_t)cap_nodes * stream::NU_COUNT * 4);
@@ -687,7 +689,9 @@ size_t carve_workspace(stream::Ws* w, char* base, uint64_t n, uint32_t ratio, ui
     w->ctrl = (stream::Ctrl*)(base + o_ctrl);
     w->rays[0] = (double*)(base + o_rays0);
     w->rays[1] = (double*)(base + o_rays1);
-    w->hits = (double*)(base + o_hits);
+    w->hit_f = (double*)(base + o_hits);
+    w->hit_prim[0] = (uint32_t*)(base + o_hp0);
+    w->hit_prim[1] = (uint32_t*)(base + o_hp1);
     w->retrace = (uint32_t*)(base + o_retrace);
     w->node_f = (double*)(base + o_nf);
     w->node_u = (uint32_t*)(base + o_nu);
@@ -1207,6 +1211,11 @@ int rt_trace_rays(const rt_scene* scene, const rt_options* options, uint32_t n, 
         b.n_samples = std::min(batch, n - at);
         b.given_o = d_o + (size_t)at * 3;
         b.given_d = d_d + (size_t)at * 3;
+        // a ray that hits nothing stores no colour: black (integrator.rs:62-65)
+        if (hipMemsetAsync(scene->ws.sample_rgb, 0, (size_t)b.n_samples * 24, 0) != hipSuccess) {
+          rc = fail(RT_ERR_DEVICE, "hipMemsetAsync(colours) failed");
+          break;
+        }
         rc = run_stream_batch<false, false>(scene, no_cam, dopt, b, 0);
         if (rc == RT_OK && hipMemcpyAsync(d_c + (size_t)at * 3, scene->ws.sample_rgb, (size_t)b.n_samples * 24, hipMemcpyDeviceToDevice, 0) != hipSuccess)
           rc = fail(RT_ERR_DEVICE, "copy of the traced colours failed");
