@@ -1112,6 +1112,10 @@ int rt_scene_create(const rt_scene_desc* d, rt_scene** out) {
   sc->dev.n_lights = d->n_lights;
   sc->dev.n_prims = d->n_prims;
   sc->n_lights = d->n_lights;
+  if (const char* e = std::getenv("RT_STREAM_NODES_PER_SAMPLE")) {  // where the adaptive ratio starts (tests start it too low)
+    unsigned long v = std::strtoul(e, nullptr, 10);
+    if (v >= 1 && v <= RT_STREAM_RATIO_MAX) sc->nodes_per_sample = (uint32_t)v;
+  }
   {
     int cus = 0;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, sc->device) == hipSuccess && cus > 0) sc->n_cus = cus;

@@ -314,3 +314,66 @@ def test_full_size_4k_production_equals_reference_order():
     assert st["overflow_pixels"] == 0 and st["rays_primary"] == 3840 * 2160 * 16
     assert float((a - b).abs().max().item()) < 1e-12
     assert float((a > 0).double().mean().item()) > 0.05
+
+
+# ---- the streamed pipeline against the single-kernel core, batches, overflow fallback -----------------------------
+def _single_kernel(opt):
+    o = type(opt)()
+    C.memmove(C.byref(o), C.byref(opt), C.sizeof(opt))
+    o.pipeline = 1
+    return o
+
+
+@pytest.mark.parametrize("name", ["images/chapters/refractions", "images/general/cover", "images/general/dragons", "animations/general/csg-lens"])
+def test_streamed_pipeline_equals_single_kernel(name):
+    """rt_options.pipeline: the streamed kernels and the one-kernel state machine run the same device functions on the same
+    operands, so their f64 pixels are identical bit for bit; so are the ray counts."""
+    kind, rel = name.split("/", 1)
+    rs = Y.load_scene(scene_path(kind, rel), width=200, height=136, depth=6, supersampling_level=3)
+    flat, cam, opt = rs.builder.flatten(), rs.camera, rs.options()
+    a, st_a = R.render(flat, cam, opt)
+    b, st_b = R.render(flat, cam, _single_kernel(opt))
+    assert np.array_equal(a, b)
+    for k in ("rays_primary", "rays_shadow", "rays_reflect", "rays_refract", "hits", "node_visits", "tri_tests", "prim_tests"):
+        assert st_a[k] == st_b[k], k
+    assert st_a["fallback_flags"] == 0
+
+
+def test_small_batches_and_overflow_fallback(monkeypatch):
+    """Many small batches, and a workspace laid out for ONE node record per sample on a scene that needs ~5: the samples
+    that do not fit are re-rendered by the fallback kernel, so the pixels do not change; the count of such events comes
+    back and the next frames get more room."""
+    torch = _torch()
+    rs = Y.load_scene(scene_path("images", "chapters/refractions"), width=168, height=120, depth=5, supersampling_level=2)
+    flat, cam, opt = rs.builder.flatten(), rs.camera, rs.options()
+    want, _ = R.render(flat, cam, opt)
+    monkeypatch.setenv("RT_STREAM_BATCH_SAMPLES", "8192")
+    monkeypatch.setenv("RT_STREAM_NODES_PER_SAMPLE", "1")
+    sc = R.DeviceScene(flat)
+    out = torch.zeros((cam.height, cam.width, 3), dtype=torch.float64, device="cuda")
+    sc.render_device(cam, opt, out.data_ptr())  # no statistics: overflowing samples go through the fallback kernel
+    torch.cuda.synchronize()
+    assert np.array_equal(out.cpu().numpy(), want)
+    for _ in range(8):  # the counts come back asynchronously: later frames are laid out with more node records
+        sc.render_device(cam, opt, out.data_ptr())
+        torch.cuda.synchronize()
+        assert np.array_equal(out.cpu().numpy(), want)
+    st = sc.render_device(cam, opt, out.data_ptr(), want_stats=True)  # a statistics launch never reports a fallback
+    assert st["fallback_flags"] == 0
+    assert np.array_equal(out.cpu().numpy(), want)
+
+
+def test_timing_mode_reports_kernel_classes():
+    torch = _torch()
+    rs = Y.load_scene(scene_path("images", "general/cover"), width=256, height=256, depth=5, supersampling_level=2)
+    flat, cam, opt = rs.builder.flatten(), rs.camera, rs.options()
+    sc = R.DeviceScene(flat)
+    out = torch.zeros((cam.height, cam.width, 3), dtype=torch.float64, device="cuda")
+    sc.render_device(cam, opt, out.data_ptr())
+    ref = out.clone()
+    opt.timing = 1
+    st = sc.render_device(cam, opt, out.data_ptr(), want_stats=True)
+    assert torch.equal(out, ref)
+    assert st["launches_trace_shadow"] >= 1 and st["launches_trace_closest"] >= opt.max_depth + 1
+    parts = sum(st[k] for k in ("ms_trace_closest", "ms_retrace", "ms_shade", "ms_trace_shadow", "ms_combine", "ms_other"))
+    assert 0 < parts <= st["ms_kernel"] * 1.05

@@ -14,4 +14,5 @@ run sq3 --pmc SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 
 run tcc1 --pmc FETCH_SIZE TCC_REQ_sum GRBM_GUI_ACTIVE &&
 run tcc2 --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum &&
 run tcp1 --pmc TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_TCC_WRITE_REQ_sum TCP_PENDING_STALL_CYCLES_sum TA_TA_BUSY_sum TA_FLAT_READ_WAVEFRONTS_sum
-find $out -name "*.csv" | head -40
+for k in trace_shadow_kernel trace_closest_kernel shade_kernel combine_kernel; do echo "== $k: mean per launch"; python3 tools/pmc_summary.py $out $k > $out/pmc_$k.json; cat $out/pmc_$k.json | tr -d '\n'; echo; done
+find $out -name "*kernel_stats.csv" | head -3
