@@ -188,12 +188,28 @@ __device__ __forceinline__ bool box_times(const double* __restrict__ bb, d3 o, d
 // The same for a ray whose dinv is finite in every component: no operand can be NaN then, and "order by a < b"
 // (bounding_box.rs:141-153) is min/max (equal values, whichever way round, compare the same afterwards), which costs 6
 // instructions per box instead of 15.
+#ifdef RT_HOST_EMU
+__device__ __forceinline__ double min_f64(double a, double b) { return fmin(a, b); }
+__device__ __forceinline__ double max_f64(double a, double b) { return fmax(a, b); }
+#else
+// v_min_f64 / v_max_f64 as they are (the compiler's fmin/fmax first quiets each operand with an extra v_max_f64 x, x)
+__device__ __forceinline__ double min_f64(double a, double b) {
+  double r;
+  asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ double max_f64(double a, double b) {
+  double r;
+  asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+#endif
 __device__ __forceinline__ bool box_times_finite(const double* __restrict__ bb, d3 o, d3 dinv, double& tmin, double& tmax) {
   double ax = (bb[0] - o.x) * dinv.x, bx = (bb[3] - o.x) * dinv.x;
   double ay = (bb[1] - o.y) * dinv.y, by = (bb[4] - o.y) * dinv.y;
   double az = (bb[2] - o.z) * dinv.z, bz = (bb[5] - o.z) * dinv.z;
-  tmin = fmax(fmax(fmin(ax, bx), fmin(ay, by)), fmin(az, bz));
-  tmax = fmin(fmin(fmax(ax, bx), fmax(ay, by)), fmax(az, bz));
+  tmin = max_f64(max_f64(min_f64(ax, bx), min_f64(ay, by)), min_f64(az, bz));
+  tmax = min_f64(min_f64(max_f64(ax, bx), max_f64(ay, by)), max_f64(az, bz));
   return !(tmin > tmax);
 }
 
@@ -205,6 +221,12 @@ __device__ __forceinline__ bool box_times_finite(const double* __restrict__ bb, 
 // candidate sets are identical and so is the hit.  Boxes are therefore kept while they are entered within the window.
 #define RT_TIE_WINDOW 1.0e-10
 __device__ __forceinline__ double near_limit(double limit) { return limit + RT_TIE_WINDOW * fmax(1., limit); }
+
+// An f32 no greater than t (and finite for every t a visited box can have): the nearest f32 moved down by its last bit.
+__device__ __forceinline__ float key_below(double t) {
+  float k = (float)t;
+  return fminf(fmaf(-fabsf(k), 1.1920929e-07f, k), 3.4028234e38f);
+}
 
 __device__ __forceinline__ void stack_push(Trav& T, uint2* lds, uint2* ovf, uint32_t ref, float t_rd, Counters& cnt) {
   uint2 e = make_uint2(ref, __float_as_uint(t_rd));
@@ -251,24 +273,46 @@ __device__ __forceinline__ void trav_run(const DevScene& s, Trav& T, uint2* lds,
     // ---- inner nodes: descend until this lane holds a leaf (or runs out of work) ----
     while ((T.cur >> RT_FREF_KIND_SHIFT) == RT_FREF_INNER) {
       if (STATS) count_step(cnt);
-      const DevNode* node = s.nodes + (T.cur & RT_FREF_INDEX_MASK);
+      // The whole node is fetched first (16-B loads, all in flight together), then tested: written out by hand because
+      // the compiler otherwise fetches and waits box by box.
+      const uint4* np = reinterpret_cast<const uint4*>(s.nodes + (T.cur & RT_FREF_INDEX_MASK));
+      constexpr int NQ = (RT_NODE_WIDTH * 7 + 3) / 4;
+      uint4 q[NQ];
+      for (int k = 0; k < NQ; k++) q[k] = np[k];
+      uint32_t raw[NQ * 4];
+      for (int k = 0; k < NQ; k++) {
+        raw[4 * k] = q[k].x;
+        raw[4 * k + 1] = q[k].y;
+        raw[4 * k + 2] = q[k].z;
+        raw[4 * k + 3] = q[k].w;
+      }
       // a box can hold an accepted intersection only if it is entered no later than the limit (plus the window in
       // which a runner-up must still be seen, see near_limit) and, for t >= 0 intersections, is not entirely behind
-      // the origin.  key = entry time rounded down to f32 (what the stack keeps), +inf for a child not to be visited.
+      // the origin.  key = a lower bound of the entry time in f32 (what the stack keeps), +inf for a child not to be visited.
       const double lim = near_limit(T.limit);
       const bool all_t = in_mode<MS>(T, M_CONTAINERS);
       float key[RT_NODE_WIDTH];
       uint32_t ref[RT_NODE_WIDTH];
-      const bool any_odd = __builtin_amdgcn_ballot_w64(T.odd != 0u) != 0ull;  // wave-uniform: a real branch, rarely taken
+      double tmin[RT_NODE_WIDTH], tmax[RT_NODE_WIDTH];
+      bool hit[RT_NODE_WIDTH];
+      if (__builtin_amdgcn_ballot_w64(T.odd != 0u) == 0ull) {  // wave-uniform: a real branch
+        for (int c = 0; c < RT_NODE_WIDTH; c++) {
+          double bb[6];
+          for (int k = 0; k < 6; k++) bb[k] = (double)__uint_as_float(raw[6 * c + k]);
+          hit[c] = box_times_finite(bb, T.o, T.dinv, tmin[c], tmax[c]);
+        }
+      } else {  // some lane's ray is parallel to an axis: the reference's operand order decides what 0 * inf does
+        for (int c = 0; c < RT_NODE_WIDTH; c++) {
+          double bb[6];
+          for (int k = 0; k < 6; k++) bb[k] = (double)__uint_as_float(raw[6 * c + k]);
+          hit[c] = box_times(bb, T.o, T.dinv, tmin[c], tmax[c]);
+        }
+      }
       for (int c = 0; c < RT_NODE_WIDTH; c++) {
-        double bb[6];
-        for (int k = 0; k < 6; k++) bb[k] = (double)node->bb[c][k];
-        ref[c] = node->ref[c];
-        double t, x;
-        bool h = any_odd ? box_times(bb, T.o, T.dinv, t, x) : box_times_finite(bb, T.o, T.dinv, t, x);
-        h = h && !(t > lim) && ref[c] != RT_FREF_NONE && (all_t || !(x < 0.));
+        ref[c] = raw[6 * RT_NODE_WIDTH + c];
+        bool h = hit[c] && !(tmin[c] > lim) && ref[c] != RT_FREF_NONE && (all_t || !(tmax[c] < 0.));
         if (STATS && ref[c] != RT_FREF_NONE) cnt.node_visits++;
-        key[c] = h ? __double2float_rd(t) : INFINITY;
+        key[c] = h ? key_below(tmin[c]) : INFINITY;
       }
       // nearest child first: sort the four (key, ref) pairs ascending (5 compare-exchanges)
 #define RT_CSWAP(a, b)                                   \
