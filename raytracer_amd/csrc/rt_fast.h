@@ -231,12 +231,8 @@ __device__ __forceinline__ float key_below(double t) {
 __device__ __forceinline__ void stack_push(Trav& T, uint2* lds, uint2* ovf, uint32_t ref, float t_rd, Counters& cnt) {
   uint2 e = make_uint2(ref, __float_as_uint(t_rd));
   if (T.sp < RT_LDS_STACK) lds[T.sp * 64] = e;
-  else if (T.sp < RT_FAST_STACK_MAX) ovf[T.sp - RT_LDS_STACK] = e;
-  else {
-    cnt.overflow = 1;
-    return;
-  }
-  T.sp++;
+  else ovf[min(T.sp - RT_LDS_STACK, RT_OVF_STACK - 1)] = e;  // cannot run over: rt_scene_create rejects a tree that needs more than
+  T.sp++;                                                     // RT_FAST_STACK_MAX entries (the clamp only keeps a bug inside the array)
 }
 
 __device__ __forceinline__ uint32_t stack_pop(Trav& T, const uint2* lds, const uint2* ovf) {
@@ -310,9 +306,11 @@ __device__ __forceinline__ void trav_run(const DevScene& s, Trav& T, uint2* lds,
       }
       for (int c = 0; c < RT_NODE_WIDTH; c++) {
         ref[c] = raw[6 * RT_NODE_WIDTH + c];
-        bool h = hit[c] && !(tmin[c] > lim) && ref[c] != RT_FREF_NONE && (all_t || !(tmax[c] < 0.));
+        // (& and |, not && and ||: four straight-line selects instead of four branches)
+        bool h = hit[c] & !(tmin[c] > lim) & (ref[c] != RT_FREF_NONE) & (all_t | !(tmax[c] < 0.));
         if (STATS && ref[c] != RT_FREF_NONE) cnt.node_visits++;
-        key[c] = h ? key_below(tmin[c]) : INFINITY;
+        float k = key_below(tmin[c]);
+        key[c] = h ? k : INFINITY;
       }
       // nearest child first: sort the four (key, ref) pairs ascending (5 compare-exchanges)
 #define RT_CSWAP(a, b)                                   \
