@@ -187,7 +187,7 @@ def main():
 
     n_pix_rank = w * h if world == 1 else D.tile_count(w, h, rank, world) * 64
     keys = ["rays_primary", "rays_shadow", "rays_reflect", "rays_refract", "node_visits", "tri_tests", "prim_tests", "hits", "hit_bytes",
-            "shadow_node_visits", "shadow_tri_tests", "shadow_prim_tests"]
+            "shadow_node_visits", "shadow_tri_tests", "shadow_prim_tests", "rays_shadow_culled"]
     tkeys = ["ms_kernel", "ms_trace_closest", "ms_retrace", "ms_shade", "ms_trace_shadow", "ms_combine", "ms_other",
              "launches_trace_closest", "launches_trace_shadow"]
     extra = [elapsed, float(algorithmic_bytes(st_ref, n_pix_rank)), float(st["lane_steps"]), float(st["wave_steps"]), xdiff,
@@ -233,6 +233,7 @@ def main():
                        "partition": "single GPU, whole frame" if world == 1 else f"8x8 tiles cyclic over {world} GPUs + gather to rank 0",
                        "rays_per_frame": rays, "primary": tot["rays_primary"], "shadow": tot["rays_shadow"],
                        "reflect": tot["rays_reflect"], "refract": tot["rays_refract"],
+                       "shadow_rays_not_traced_light_behind_surface": tot["rays_shadow_culled"],
                        "pipeline": "single kernel" if opt.pipeline else "streamed", "host_scene_prep_s": round(t_prep, 2)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,

@@ -198,6 +198,9 @@ typedef struct rt_stats {
   uint64_t shadow_node_visits, shadow_tri_tests, shadow_prim_tests; /* streamed pipeline: the part of node_visits / tri_tests /
                               prim_tests done by trace_shadow_kernel */
   uint64_t shadow_wave_steps, shadow_lane_steps, shadow_clocks_node, shadow_clocks_leaf, shadow_clocks_total; /* likewise */
+  uint64_t rays_shadow_culled; /* streamed pipeline: (hit, light) pairs whose shadow ray was NOT traced (and is not in rays_shadow)
+                              because the light is behind the surface: there point_light.rs:50-55 returns the ambient term
+                              without using the shadow value.  rays_shadow + rays_shadow_culled = the reference's shadow rays */
   uint64_t launches_trace_closest, launches_trace_shadow; /* rt_options.timing: launches behind the ms_* sums below */
   uint64_t fallback_flags; /* streamed pipeline: times a ray or hit found its batch's queues full; the samples concerned were
                               re-rendered by the single-kernel state machine (same pixels, slower).  0 in a well-sized batch */

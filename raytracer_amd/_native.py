@@ -63,7 +63,7 @@ class rt_stats(C.Structure):
                 ("rays_refract", C.c_uint64), ("node_visits", C.c_uint64), ("tri_tests", C.c_uint64),
                 ("prim_tests", C.c_uint64), ("hits", C.c_uint64), ("hit_bytes", C.c_uint64), ("overflow_pixels", C.c_uint64),
                 ("wave_steps", C.c_uint64), ("lane_steps", C.c_uint64), ("rays_retraced", C.c_uint64), ("clocks_traversal", C.c_uint64),
-                ("clocks_machine", C.c_uint64), ("clocks_trace_total", C.c_uint64), ("shadow_node_visits", C.c_uint64), ("shadow_tri_tests", C.c_uint64), ("shadow_prim_tests", C.c_uint64), ("shadow_wave_steps", C.c_uint64), ("shadow_lane_steps", C.c_uint64), ("shadow_clocks_node", C.c_uint64), ("shadow_clocks_leaf", C.c_uint64), ("shadow_clocks_total", C.c_uint64), ("launches_trace_closest", C.c_uint64), ("launches_trace_shadow", C.c_uint64), ("fallback_flags", C.c_uint64), ("ms_upload", C.c_double),
+                ("clocks_machine", C.c_uint64), ("clocks_trace_total", C.c_uint64), ("shadow_node_visits", C.c_uint64), ("shadow_tri_tests", C.c_uint64), ("shadow_prim_tests", C.c_uint64), ("shadow_wave_steps", C.c_uint64), ("shadow_lane_steps", C.c_uint64), ("shadow_clocks_node", C.c_uint64), ("shadow_clocks_leaf", C.c_uint64), ("shadow_clocks_total", C.c_uint64), ("rays_shadow_culled", C.c_uint64), ("launches_trace_closest", C.c_uint64), ("launches_trace_shadow", C.c_uint64), ("fallback_flags", C.c_uint64), ("ms_upload", C.c_double),
                 ("ms_kernel", C.c_double), ("ms_download", C.c_double), ("ms_trace_closest", C.c_double), ("ms_retrace", C.c_double), ("ms_shade", C.c_double), ("ms_trace_shadow", C.c_double), ("ms_combine", C.c_double), ("ms_other", C.c_double)]
 
     def as_dict(self):

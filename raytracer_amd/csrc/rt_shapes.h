@@ -9,6 +9,7 @@ struct Counters {
   uint32_t retraced;                // fast path: rays settled by the reference-order walk (coincident surfaces)
   uint32_t cyc_trav, cyc_adv;       // statistics builds: shader clocks / 64 spent traversing / in the state machine (single kernel);
                                     // wavefront clocks / 64 in the node loop / in leaves (streamed trace kernels)
+  uint32_t shadow_culled;           // streamed pipeline: shadow rays not traced because the light is behind the surface
   uint32_t cyc_total;               // streamed trace kernels: wavefront clocks / 64 from the kernel's start to its end
 };
 

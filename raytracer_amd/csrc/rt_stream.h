@@ -534,12 +534,18 @@ __global__ void close_level_kernel(Ws w, uint32_t level) {
 // Item id = light * n_nodes + node: a wavefront's lanes hold neighbouring nodes and the same light (a lane that walked
 // through its node's lights in turn was measured 10 % slower: the lanes of a wavefront then face different lights).
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ void shadow_start(const DevScene& s, fast::Trav& T, d3 over, uint32_t l) {
+// Sets up the shadow ray of (over_point, light l) — unless the light is behind the surface.  There
+// color_of_illuminated_point returns the ambient term without looking at the shadow value (point_light.rs:50-55:
+// `approx_eq(shadow, 1) || light_v.dot(normal) < 0`), and light_v = normalize(light - over_point) is exactly the shadow
+// ray's direction (integrator.rs:110-123), so the ray's result cannot reach a pixel and it is not traced.
+__device__ __forceinline__ bool shadow_start(const DevScene& s, fast::Trav& T, d3 over, d3 normal, uint32_t l) {
   const double* lp = s.light_pos + (size_t)l * 3;
   d3 vv = sub3(mk3(lp[0], lp[1], lp[2]), over);  // get_point_shadow_dist_ray (integrator.rs:110-123)
   double dist = mag3(vv);
   d3 sdir = normalize3(vv);
+  if (dot3(sdir, normal) < 0.) return false;
   fast::trav_start(T, over, sdir, fast::M_SHADOW, dist);
+  return true;
 }
 
 template <bool STATS>
@@ -571,8 +577,14 @@ __global__ __launch_bounds__(64, RT_TRACE_WAVES) void trace_shadow_kernel(DevSce
           my = id - light * n_nodes;
           const double* nf = w.node_f + my;
           d3 over = mk3(nf[(NF_OVER + 0) * cap], nf[(NF_OVER + 1) * cap], nf[(NF_OVER + 2) * cap]);
-          if (STATS) cnt.rays_shadow++;
-          shadow_start(s, T, over, light);
+          d3 normal = mk3(nf[(NF_NORMAL + 0) * cap], nf[(NF_NORMAL + 1) * cap], nf[(NF_NORMAL + 2) * cap]);
+          if (shadow_start(s, T, over, normal, light)) {
+            if (STATS) cnt.rays_shadow++;
+          } else {  // the light is behind the surface: no ray
+            if (STATS) cnt.shadow_culled++;
+            w.shadow[(size_t)light * cap + my] = 0.;
+            my = RT_NONE;
+          }
         } else {
           exhausted = true;
         }

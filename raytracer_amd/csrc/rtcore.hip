@@ -17,7 +17,7 @@
 // ---------------------------------------------------------------------------------------------
 // kernels
 // ---------------------------------------------------------------------------------------------
-#define RT_N_COUNTERS 25
+#define RT_N_COUNTERS 26
 #define RT_COUNTER_SHADOW 17  // streamed pipeline: trace_shadow_kernel's own box / triangle / primitive tests, wave / lane steps, node / leaf / total clocks (8 slots)
 #define RT_COUNTER_FALLBACK 15  // streamed pipeline: flag events of samples handed to the fallback kernel
 #ifndef RT_WAVES_PER_EU
@@ -40,8 +40,8 @@ __device__ __forceinline__ void flush_counters(const Counters& c, unsigned long 
 
 // trace_shadow_kernel's share of the traversal counters, kept apart for its roofline (bench.py).
 __device__ __forceinline__ void flush_shadow_counters(const Counters& c, unsigned long long* stats) {
-  uint32_t v[8] = {c.node_visits, c.tri_tests, c.prim_tests, c.wave_steps, c.lane_steps, c.cyc_trav, c.cyc_adv, c.cyc_total};
-  for (int k = 0; k < 8; k++) {
+  uint32_t v[9] = {c.node_visits, c.tri_tests, c.prim_tests, c.wave_steps, c.lane_steps, c.cyc_trav, c.cyc_adv, c.cyc_total, c.shadow_culled};
+  for (int k = 0; k < 9; k++) {
     unsigned long long x = v[k];
     for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
     if ((threadIdx.x & 63) == 0 && x) atomicAdd(&stats[RT_COUNTER_SHADOW + k], x);
@@ -960,6 +960,7 @@ int launch_render_once(const rt_scene* scene, const rt_camera* cam, const rt_opt
     stats->shadow_clocks_node = h[RT_COUNTER_SHADOW + 5] * 64;
     stats->shadow_clocks_leaf = h[RT_COUNTER_SHADOW + 6] * 64;
     stats->shadow_clocks_total = h[RT_COUNTER_SHADOW + 7] * 64;
+    stats->rays_shadow_culled = h[RT_COUNTER_SHADOW + 8];
     double* ms_class[TC_COUNT] = {&stats->ms_trace_closest, &stats->ms_retrace, &stats->ms_shade, &stats->ms_trace_shadow,
                                   &stats->ms_combine,       &stats->ms_other};
     for (size_t i = 0; i < scene->timed_class.size(); i++) {
