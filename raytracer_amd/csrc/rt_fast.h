@@ -49,7 +49,8 @@ struct Trav {
   uint32_t mode;
   uint32_t odd;   // 1: a component of dinv is not finite (an axis-parallel ray): 0 * inf = NaN can occur in the slab test,
                   // whose outcome then depends on the reference's operand order (see box_times)
-  uint32_t cur;   // reference being visited, RT_FREF_NONE when the traversal is complete
+  uint32_t cur;   // reference being visited, RT_FREF_NONE when nothing is left to visit
+  uint32_t pending;  // RT_SPECULATE: a leaf reached but not yet intersected (the lane went on down the tree meanwhile)
   int sp;
 };
 
@@ -61,6 +62,7 @@ __device__ __forceinline__ void trav_start(Trav& T, d3 o, d3 d, uint32_t mode, d
   T.mode = mode;
   T.odd = (fabs(T.dinv.x) < INFINITY && fabs(T.dinv.y) < INFINITY && fabs(T.dinv.z) < INFINITY) ? 0u : 1u;
   T.cur = RT_MAKE_FREF(RT_FREF_INNER, 0, 0);
+  T.pending = RT_FREF_NONE;
   T.sp = 0;
   if (mode == M_CLOSEST) {
     T.p = RT_NONE;
@@ -258,16 +260,32 @@ __device__ __forceinline__ void count_step(Counters& cnt) {  // statistics build
   if ((uint32_t)(__ffsll((long long)active) - 1) == (threadIdx.x & 63u)) cnt.wave_steps++;
 }
 
-// Runs the lane's traversal to completion (lanes whose T.cur is RT_FREF_NONE have nothing to do).
+// RT_SPECULATE = 1: a lane that reaches a leaf while other lanes of its wavefront are still descending does not wait for
+// them: it keeps the leaf as `pending`, pops its stack and goes on descending; the pending leaf is intersected when the
+// wavefront next does leaves.  More lanes are busy in both phases; the price is box tests a nearer hit in the pending leaf
+// would have culled (never a different result: culling by the limit is only ever an optimisation).
+#ifndef RT_SPECULATE
+#define RT_SPECULATE 0
+#endif
+__device__ __forceinline__ bool trav_busy(const Trav& T) {
+  return T.cur != RT_FREF_NONE || (RT_SPECULATE && T.pending != RT_FREF_NONE);
+}
+
+// Runs the lane's traversal to completion (lanes that are not trav_busy have nothing to do).
 // min_active > 0 (the streamed kernels, rt_stream.h): the loop is left, with the unfinished lanes' state intact, as soon as
 // fewer than min_active lanes of the wavefront are still traversing, so that the idle ones can fetch their next ray.
 template <bool STATS, int MS = MS_ALL>
 __device__ __forceinline__ void trav_run(const DevScene& s, Trav& T, uint2* lds, uint2* ovf, Counters& cnt, uint32_t min_active = 0) {
-  while (T.cur != RT_FREF_NONE) {
+  while (trav_busy(T)) {
     if (min_active && (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(true)) < min_active) break;
     unsigned long long tc0 = (STATS && min_active) ? (unsigned long long)clock64() : 0ull;
     // ---- inner nodes: descend until this lane holds a leaf (or runs out of work) ----
-    while ((T.cur >> RT_FREF_KIND_SHIFT) == RT_FREF_INNER) {
+    for (;;) {
+      if (RT_SPECULATE && T.pending == RT_FREF_NONE && T.cur != RT_FREF_NONE && (T.cur >> RT_FREF_KIND_SHIFT) != RT_FREF_INNER) {
+        T.pending = T.cur;
+        T.cur = stack_pop(T, lds, ovf);
+      }
+      if ((T.cur >> RT_FREF_KIND_SHIFT) != RT_FREF_INNER) break;
       if (STATS) count_step(cnt);
       // The whole node is fetched first (16-B loads, all in flight together), then tested: written out by hand because
       // the compiler otherwise fetches and waits box by box.
@@ -338,11 +356,12 @@ __device__ __forceinline__ void trav_run(const DevScene& s, Trav& T, uint2* lds,
     }
     unsigned long long tc1 = (STATS && min_active) ? (unsigned long long)clock64() : 0ull;
     if (STATS && min_active && first_active_lane()) cnt.cyc_trav += (uint32_t)((tc1 - tc0) >> 6);
-    if (T.cur == RT_FREF_NONE) break;
+    const uint32_t leaf = RT_SPECULATE ? T.pending : T.cur;
+    if (leaf == RT_FREF_NONE) break;
     // ---- leaf ----
     if (STATS) count_step(cnt);
-    uint32_t kind = T.cur >> RT_FREF_KIND_SHIFT;
-    uint32_t count = (T.cur >> RT_FREF_COUNT_SHIFT) & RT_FREF_COUNT_MASK, first = T.cur & RT_FREF_INDEX_MASK;
+    uint32_t kind = leaf >> RT_FREF_KIND_SHIFT;
+    uint32_t count = (leaf >> RT_FREF_COUNT_SHIFT) & RT_FREF_COUNT_MASK, first = leaf & RT_FREF_INDEX_MASK;
     if (kind == RT_FREF_TRIS) {
       for (uint32_t j = 0; j < count; j++) {
         const double* tri = s.tri_isect + (size_t)(first + j) * RT_TRI_STRIDE;
@@ -369,10 +388,11 @@ __device__ __forceinline__ void trav_run(const DevScene& s, Trav& T, uint2* lds,
       }
     }
     if (STATS && min_active && first_active_lane()) cnt.cyc_adv += (uint32_t)(((unsigned long long)clock64() - tc1) >> 6);
+    if (RT_SPECULATE) T.pending = RT_FREF_NONE;
     if (in_mode<MS>(T, M_SHADOW) && T.a >= 1.) {  // min(intensity, 1) is already 1 (intersection.rs:124-126)
       T.cur = RT_FREF_NONE;
       T.sp = 0;
-    } else {
+    } else if (!RT_SPECULATE) {
       T.cur = stack_pop(T, lds, ovf);
     }
   }
@@ -461,6 +481,7 @@ __device__ __forceinline__ void run_machine(const DevScene& s, const DevOptions&
   Frame frames[RT_FRAMES];
   Trav T;
   T.cur = RT_FREF_NONE;
+  T.pending = RT_FREF_NONE;
   T.sp = 0;
   T.mode = M_CLOSEST;
   T.limit = 0.;

@@ -289,6 +289,7 @@ __global__ __launch_bounds__(64, RT_CLOSEST_WAVES) void trace_closest_kernel(Dev
   const double* __restrict__ queue = w.rays[level & 1];
   fast::Trav T;
   T.cur = RT_FREF_NONE;
+  T.pending = RT_FREF_NONE;
   T.sp = 0;
   T.mode = fast::M_CLOSEST;
   T.limit = 0.;
@@ -323,7 +324,7 @@ __global__ __launch_bounds__(64, RT_CLOSEST_WAVES) void trace_closest_kernel(Dev
         }
       }
     }
-    if (__builtin_amdgcn_ballot_w64(T.cur != RT_FREF_NONE) == 0ull) {
+    if (__builtin_amdgcn_ballot_w64(fast::trav_busy(T)) == 0ull) {
       if (__builtin_amdgcn_ballot_w64(!exhausted) == 0ull) break;
       continue;
     }
@@ -331,7 +332,7 @@ __global__ __launch_bounds__(64, RT_CLOSEST_WAVES) void trace_closest_kernel(Dev
     uint32_t min_active = __builtin_amdgcn_ballot_w64(exhausted) != 0ull ? 0u : (uint32_t)RT_REFILL_BELOW;
     fast::trav_run<STATS, fast::MS_CLOSEST_CONTAINERS>(s, T, lds, ovf, cnt, min_active);
     // ---- lanes whose traversal is complete ----
-    if (my != RT_NONE && T.cur == RT_FREF_NONE) {
+    if (my != RT_NONE && !fast::trav_busy(T)) {
       if (T.mode == fast::M_CLOSEST) {
         if (T.p == RT_NONE) {  // miss
           store_hit(w, level, my, RT_NONE, 0., 0., 0., 0., 0.);
@@ -560,6 +561,7 @@ __global__ __launch_bounds__(64, RT_TRACE_WAVES) void trace_shadow_kernel(DevSce
   const size_t cap = w.cap_nodes;
   fast::Trav T;
   T.cur = RT_FREF_NONE;
+  T.pending = RT_FREF_NONE;
   T.sp = 0;
   T.mode = fast::M_SHADOW;
   T.limit = 0.;
@@ -590,13 +592,13 @@ __global__ __launch_bounds__(64, RT_TRACE_WAVES) void trace_shadow_kernel(DevSce
         }
       }
     }
-    if (__builtin_amdgcn_ballot_w64(T.cur != RT_FREF_NONE) == 0ull) {
+    if (__builtin_amdgcn_ballot_w64(fast::trav_busy(T)) == 0ull) {
       if (__builtin_amdgcn_ballot_w64(!exhausted) == 0ull) break;
       continue;
     }
     uint32_t min_active = __builtin_amdgcn_ballot_w64(exhausted) != 0ull ? 0u : (uint32_t)RT_REFILL_BELOW;
     fast::trav_run<STATS, fast::MS_SHADOW>(s, T, lds, ovf, cnt, min_active);
-    if (my != RT_NONE && T.cur == RT_FREF_NONE) {
+    if (my != RT_NONE && !fast::trav_busy(T)) {
       w.shadow[(size_t)light * cap + my] = T.a;
       my = RT_NONE;
     }
