@@ -48,12 +48,12 @@ enum { NU_PRIM = 0, NU_PARENT = 1, NU_ROOT = 2, NU_COUNT = 3 };
 
 struct Ctrl {  // device-resident control block of one batch; zeroed when the batch starts
   uint32_t n_rays[RT_LEVELS + 1];  // rays queued for each level (level 0: unused, its rays are the batch's samples)
-  uint32_t fetch[RT_LEVELS][8];    // trace_closest: next ray of the level in each XCD's share (xcd_take)
+  uint32_t fetch[RT_LEVELS][9];    // trace_closest: next ray of the level in each XCD's share; [8]: used-up shares (xcd_take)
   uint32_t n_retrace[RT_LEVELS];
   uint32_t level_end[RT_LEVELS];   // nodes [level_end[l-1], level_end[l]) belong to level l
   uint32_t n_nodes;                // nodes allocated (may run past cap_nodes; clamped in level_end)
   uint32_t n_flagged;              // samples handed to the fallback
-  uint32_t shadow_fetch[8];        // trace_shadow: next (light, node) item in each XCD's share
+  uint32_t shadow_fetch[9];        // trace_shadow: next (light, node) item in each XCD's share; [8]: used-up shares
 };
 
 struct Ws {  // workspace of one batch (device pointers; owned by rt_scene)
@@ -110,21 +110,31 @@ __device__ __forceinline__ uint32_t wave_take(uint32_t* counter, bool want) {
 // up takes from the next XCD's (`victim`, only ever advances).
 // A wavefront does not go to the counter for every refill: returning atomics on one address are served one after the
 // other (~90 ns each), which at 64 rays per atomic bounded the trace kernels at ~0.7 G rays/s per counter.  It takes
-// RT_XCD_GRAB items at a time and hands them to its lanes from that private range.  All cursor fields are wave-uniform.
+// up to RT_XCD_GRAB items at a time and hands them to its lanes from that private range.  All cursor fields are wave-uniform.
 #ifndef RT_XCD_CHUNK
 #define RT_XCD_CHUNK 65536u
 #endif
 #ifndef RT_XCD_GRAB
-#define RT_XCD_GRAB 1024u  // divides RT_XCD_CHUNK
+#define RT_XCD_GRAB 1024u
 #endif
 struct XcdCursor {
   uint32_t xcd, victim, next, end;  // [next, end): items of XCD (xcd + victim) & 7's share this wavefront has taken
   uint32_t grab;                    // items per atomic: 64 .. RT_XCD_GRAB, so that every wavefront still gets several turns
+  uint32_t done;                    // bit x: XCD x's share is known to be used up
 };
 __device__ __forceinline__ XcdCursor xcd_cursor(uint32_t n_items) {
   uint32_t grab = 64u;
   while (grab < RT_XCD_GRAB && (unsigned long long)grab * gridDim.x * 8u < n_items) grab <<= 1;
-  return XcdCursor{blockIdx.x & 7u, 0u, 0u, 0u, grab};
+  return XcdCursor{blockIdx.x & 7u, 0u, 0u, 0u, grab, 0u};
+}
+
+// Number of items in XCD xx's share: q in [0, share) <-> item ((q / CHUNK) * 8 + xx) * CHUNK + q % CHUNK < n_items.
+__device__ __forceinline__ uint32_t xcd_share(uint32_t n_items, uint32_t xx) {
+  uint32_t n_chunks = (n_items + RT_XCD_CHUNK - 1u) / RT_XCD_CHUNK;
+  if (n_chunks <= xx) return 0u;
+  uint32_t mine = (n_chunks - xx + 7u) / 8u, share = mine * RT_XCD_CHUNK;
+  if ((n_chunks - 1u) % 8u == xx) share -= n_chunks * RT_XCD_CHUNK - n_items;  // the ragged last chunk is this XCD's
+  return share;
 }
 
 // Every lane with `want` gets a distinct item id < n_items, or RT_NONE when nothing is left.
@@ -136,25 +146,37 @@ __device__ __forceinline__ uint32_t xcd_take(uint32_t* counters, uint32_t n_item
     if (m == 0ull) break;
     uint32_t xx = (c.xcd + c.victim) & 7u;
     if (c.next == c.end) {  // take the next c.grab items of that XCD's share
+      uint32_t share = xcd_share(n_items, xx);
+      if (share == 0u || ((c.done >> xx) & 1u)) {  // nothing there, or known to be used up
+        c.victim++;
+        continue;
+      }
       uint32_t q = 0;
       if (w && rank_in(m) == 0) q = atomicAdd(&counters[xx], c.grab);
       q = __builtin_amdgcn_readfirstlane(__shfl(q, __ffsll((long long)m) - 1, 64));
+      if (q >= share) {
+        // Used up.  Word 8 of the counters collects the used-up shares: when a kernel drains, every wavefront would
+        // otherwise try all 8 counters, and 3072 wavefronts x 8 returning atomics on 8 addresses took ~250 us per
+        // launch, work or no work.
+        uint32_t seen = __hip_atomic_load(&counters[8], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (w && rank_in(m) == 0 && !((seen >> xx) & 1u)) atomicOr(&counters[8], 1u << xx);
+        c.done |= __builtin_amdgcn_readfirstlane(__shfl(seen, __ffsll((long long)m) - 1, 64)) | (1u << xx);
+        c.victim++;
+        continue;
+      }
       c.next = q;
-      c.end = q + c.grab;
+      c.end = min(q + c.grab, share);
+      // guided: the nearer the share's end, the smaller the next grab, so that no wavefront sits on a long private range
+      // while the others have run dry
+      uint32_t left = share - c.end;
+      c.grab = min(max((left / max(gridDim.x / 4u, 1u)) & ~63u, 64u), (uint32_t)RT_XCD_GRAB);
     }
     uint32_t avail = c.end - c.next, r = rank_in(m);
-    bool failed = false;
     if (w && r < avail) {
       uint32_t q = c.next + r;
-      unsigned long long g = ((unsigned long long)(q / RT_XCD_CHUNK) * 8u + xx) * RT_XCD_CHUNK + q % RT_XCD_CHUNK;
-      if (g < n_items) id = (uint32_t)g;
-      else failed = true;
+      id = ((q / RT_XCD_CHUNK) * 8u + xx) * RT_XCD_CHUNK + q % RT_XCD_CHUNK;
     }
     c.next += min(avail, (uint32_t)__builtin_popcountll(m));
-    if (__builtin_amdgcn_ballot_w64(failed) != 0ull) {  // ids only grow: that share is used up
-      c.victim++;
-      c.next = c.end = 0;
-    }
   }
   return id;
 }

@@ -40,6 +40,8 @@ static inline long long clock64() { return 0; }
 static inline int __ffsll(long long v) { return __builtin_ffsll(v); }
 template <class T> static inline T __shfl_down(T, int, int) { return T(0); }
 template <class T> static inline T __shfl(T v, int, int) { return v; }
+#define __HIP_MEMORY_SCOPE_AGENT 0
+template <class T> static inline T __hip_atomic_load(T* p, int, int) { return *p; }
 template <class T> static inline T atomicAdd(T* p, T v) { T o = *p; *p += v; return o; }
 static inline uint32_t atomicOr(uint32_t* p, uint32_t v) { uint32_t o = *p; *p |= v; return o; }
 
@@ -51,6 +53,7 @@ enum { hipSuccess = 0 };
 enum hipMemcpyKind { hipMemcpyHostToDevice, hipMemcpyDeviceToHost, hipMemcpyDeviceToDevice };
 static inline const char* hipGetErrorString(hipError_t) { return "host emulation"; }
 static inline uint32_t min(uint32_t a, uint32_t b) { return a < b ? a : b; }
+static inline uint32_t max(uint32_t a, uint32_t b) { return a > b ? a : b; }
 static inline uint32_t __builtin_amdgcn_mbcnt_lo(uint32_t, uint32_t v) { return v; }  // single lane: nothing below it
 static inline uint32_t __builtin_amdgcn_mbcnt_hi(uint32_t, uint32_t v) { return v; }
 static inline uint32_t __builtin_amdgcn_readfirstlane(uint32_t v) { return v; }
