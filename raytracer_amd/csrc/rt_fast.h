@@ -224,6 +224,13 @@ __device__ __forceinline__ bool box_times_finite(const double* __restrict__ bb, 
 #define RT_TIE_WINDOW 1.0e-10
 __device__ __forceinline__ double near_limit(double limit) { return limit + RT_TIE_WINDOW * fmax(1., limit); }
 
+// Keeps the compiler from sinking these loads below a later branch: they are all issued, and waited for, here.
+__device__ __forceinline__ void pin_loaded(double2& a, double2& b, double2& c, double2& d, double2& e) {
+#ifndef RT_HOST_EMU
+  asm volatile("" : "+v"(a.x), "+v"(a.y), "+v"(b.x), "+v"(b.y), "+v"(c.x), "+v"(c.y), "+v"(d.x), "+v"(d.y), "+v"(e.x), "+v"(e.y));
+#endif
+}
+
 // An f32 no greater than t (and finite for every t a visited box can have): the nearest f32 moved down by its last bit.
 __device__ __forceinline__ float key_below(double t) {
   float k = (float)t;
@@ -364,7 +371,11 @@ __device__ __forceinline__ void trav_run(const DevScene& s, Trav& T, uint2* lds,
     uint32_t count = (leaf >> RT_FREF_COUNT_SHIFT) & RT_FREF_COUNT_MASK, first = leaf & RT_FREF_INDEX_MASK;
     if (kind == RT_FREF_TRIS) {
       for (uint32_t j = 0; j < count; j++) {
-        const double* tri = s.tri_isect + (size_t)(first + j) * RT_TRI_STRIDE;
+        // the whole 80-B record in one go (the compiler would fetch p1 only after the determinant test: a second round trip)
+        const double2* tp = reinterpret_cast<const double2*>(s.tri_isect + (size_t)(first + j) * RT_TRI_STRIDE);
+        double2 r0 = tp[0], r1 = tp[1], r2 = tp[2], r3 = tp[3], r4 = tp[4];
+        pin_loaded(r0, r1, r2, r3, r4);
+        const double tri[RT_TRI_STRIDE] = {r0.x, r0.y, r1.x, r1.y, r2.x, r2.y, r3.x, r3.y, r4.x, r4.y};
         double t, u, v;
         if (STATS) cnt.tri_tests++;
         if (triangle_roots(tri, T.o, T.d, &t, u, v)) {

@@ -455,7 +455,11 @@ __global__ __launch_bounds__(256) void shade_kernel(DevScene s, rt_camera cam, D
     d3 o = mk3(0., 0., 0.), d = mk3(0., 0., 1.);
     uint32_t parent = id, root = id;  // level 0: the sample
     if (valid && level != 0) load_ray(queue, id, o, d, parent, root);
+#ifdef RT_EXP_NO_NODE_ATOMIC  // timing experiment only (wrong pixels): what the node-allocation atomic costs
+    uint32_t node = id;
+#else
     uint32_t node = wave_take(&w.ctrl->n_nodes, hit);
+#endif
     if (hit && node >= w.cap_nodes) {  // no room for this hit: the whole sample goes to the fallback
       flag_sample(w, root);
       hit = false;

@@ -22,6 +22,7 @@
 
 struct uint2 { uint32_t x, y; };
 struct uint4 { uint32_t x, y, z, w; };
+struct double2 { double x, y; };
 static inline uint2 make_uint2(uint32_t x, uint32_t y) { return uint2{x, y}; }
 static inline uint4 make_uint4(uint32_t x, uint32_t y, uint32_t z, uint32_t w) { return uint4{x, y, z, w}; }
 struct dim3 { unsigned x, y, z; dim3(unsigned a = 1, unsigned b = 1, unsigned c = 1) : x(a), y(b), z(c) {} };
