@@ -100,9 +100,25 @@ struct __attribute__((aligned(16))) DevEntry {
   uint32_t pad;
 };
 
+// One entry of a PRIMS leaf, self-contained: testing an analytic primitive is ONE 128-B fetch instead of the chain
+// leaf_ref -> prim_info -> xform_inv / quadric.  Rows 0-2 of the inverse transform (row 3 is 0,0,0,1 and is not read by
+// the intersection code); triangles and CSG objects inside such leaves keep the table path (flags say so).
+#define RT_LEAFREC_INLINE 1u   // flags: shape / matrix / y range below are valid (an analytic primitive)
+#define RT_LEAFREC_XFORM 2u    // flags: the primitive has a transformation_inverse (object.rs:432-439)
+#define RT_LEAFREC_CLOSED 4u   // flags: cylinder / cone is closed
+struct __attribute__((aligned(128))) DevLeafRec {
+  uint32_t ref;       // RT_MAKE_REF(kind, index), as in leaf_ref
+  uint32_t shape;     // enum rt_shape
+  uint32_t material;
+  uint32_t flags;
+  double inv[12];     // rows 0..2 of transformation_inverse
+  double y_min, y_max;
+};
+
 struct DevScene {
   const DevNode* nodes;       // fast path; node 0 is a synthetic root whose child 0 is the scene's root group
   const uint32_t* leaf_ref;   // fast path: primitive / CSG references of PRIMS leaves
+  const DevLeafRec* leaf_rec; // fast path: the same entries with everything an analytic primitive's test reads, 128 B each
   const uint32_t* prim_rank;  // visit order of each primitive in ObjectGroup::intersect_iter (decides ties in t)
   const DevEntry* entries;    // reference-order path
   const uint4* prim_info;     // x shape, y material, z xform (RT_NONE = none), w geom (triangles: index in leaf order)

@@ -386,9 +386,22 @@ __device__ __forceinline__ void trav_run(const DevScene& s, Trav& T, uint2* lds,
       }
     } else {  // RT_FREF_PRIMS
       for (uint32_t j = 0; j < count; j++) {
-        uint32_t ref = s.leaf_ref[first + j];
+        // the whole 128-B entry in one go
+        const uint4* rp = reinterpret_cast<const uint4*>(s.leaf_rec + (first + j));
+        uint4 h0 = rp[0];
+        double2 m0 = reinterpret_cast<const double2*>(rp)[1], m1 = reinterpret_cast<const double2*>(rp)[2],
+                m2 = reinterpret_cast<const double2*>(rp)[3], m3 = reinterpret_cast<const double2*>(rp)[4],
+                m4 = reinterpret_cast<const double2*>(rp)[5], m5 = reinterpret_cast<const double2*>(rp)[6],
+                yr = reinterpret_cast<const double2*>(rp)[7];
+        uint32_t ref = h0.x;
         uint32_t idx = ref & RT_REF_INDEX_MASK;
-        if ((ref >> RT_REF_KIND_SHIFT) == RT_REF_PRIM) {
+        if (h0.w & RT_LEAFREC_INLINE) {
+          pin_loaded(m0, m1, m2, m3, m4);
+          const double inv[12] = {m0.x, m0.y, m1.x, m1.y, m2.x, m2.y, m3.x, m3.y, m4.x, m4.y, m5.x, m5.y};
+          double ts[4], u, v;
+          int n = analytic_roots<STATS>(h0.y, h0.w, inv, yr.x, yr.y, T.o, T.d, T.dinv, ts, u, v, cnt);
+          if (n) add_roots<STATS, MS>(s, T, idx, h0.z, n, ts, u, v);
+        } else if ((ref >> RT_REF_KIND_SHIFT) == RT_REF_PRIM) {
           uint4 info = s.prim_info[idx];
           double ts[4], u, v;
           int n = prim_roots<STATS>(s, info, T.o, T.d, T.dinv, ts, u, v, cnt);

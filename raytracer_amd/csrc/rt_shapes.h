@@ -193,6 +193,28 @@ __device__ __forceinline__ int prim_roots(const DevScene& s, uint4 info, d3 o, d
   }
 }
 
+// The same for an analytic primitive whose record is already in registers (DevLeafRec: rt_fast.h's PRIMS leaves).
+template <bool STATS>
+__device__ __forceinline__ int analytic_roots(uint32_t shape, uint32_t flags, const double* __restrict__ inv, double y_min, double y_max,
+                                              d3 o, d3 d, d3 dinv, double* ts, double& u, double& v, Counters& cnt) {
+  u = -INFINITY;
+  v = -INFINITY;
+  if (STATS) cnt.prim_tests++;
+  if (flags & RT_LEAFREC_XFORM) {  // Ray::transform_new (ray.rs:21-23) -> Ray::new recomputes dir_inv (ray.rs:27-34)
+    o = mat_point(inv, o);
+    d = mat_vector(inv, d);
+    dinv = mk3(1. / d.x, 1. / d.y, 1. / d.z);
+  }
+  switch (shape) {
+    case RT_SHAPE_SPHERE: return sphere_roots(o, d, ts);
+    case RT_SHAPE_PLANE: return plane_roots(o, d, ts);
+    case RT_SHAPE_CUBE:
+    case RT_SHAPE_BBOX: return cube_roots(o, dinv, ts);
+    case RT_SHAPE_CYLINDER: return cylinder_roots(o, d, y_min, y_max, (flags & RT_LEAFREC_CLOSED) != 0, ts);
+    default: return cone_roots(o, d, y_min, y_max, (flags & RT_LEAFREC_CLOSED) != 0, ts);
+  }
+}
+
 #define RT_CSG_LIST_MAX 16   // hits kept per outermost CSG evaluation
 #define RT_CSG_NEST_MAX 4    // nested CSG objects
 

@@ -1089,6 +1089,31 @@ int rt_scene_create(const rt_scene_desc* d, rt_scene** out) {
   } while (0)
   UP(L.nodes, nodes);
   UP(L.leaf_ref, leaf_ref);
+  {
+    std::vector<DevLeafRec> recs(L.leaf_ref.size());
+    for (size_t i = 0; i < recs.size(); i++) {
+      DevLeafRec& r = recs[i];
+      std::memset(&r, 0, sizeof(r));
+      r.ref = L.leaf_ref[i];
+      if ((r.ref >> RT_REF_KIND_SHIFT) != RT_REF_PRIM) continue;
+      uint32_t p = r.ref & RT_REF_INDEX_MASK;
+      uint8_t sh = d->prim_shape[p];
+      if (sh == RT_SHAPE_TRIANGLE || sh == RT_SHAPE_SMOOTH_TRIANGLE) continue;  // table path (prim_roots)
+      r.shape = sh;
+      r.material = d->prim_material[p];
+      r.flags = RT_LEAFREC_INLINE;
+      if (d->prim_xform[p] != RT_NONE) {
+        r.flags |= RT_LEAFREC_XFORM;
+        std::memcpy(r.inv, d->xform_inv + (size_t)d->prim_xform[p] * 16, sizeof(r.inv));
+      }
+      if (sh == RT_SHAPE_CYLINDER || sh == RT_SHAPE_CONE) {
+        r.y_min = d->quadric_y_min[d->prim_geom[p]];
+        r.y_max = d->quadric_y_max[d->prim_geom[p]];
+        if (d->quadric_closed[d->prim_geom[p]]) r.flags |= RT_LEAFREC_CLOSED;
+      }
+    }
+    UP(recs, leaf_rec);
+  }
   UP(L.prim_rank, prim_rank);
   UP(entries, entries);
   UP(prim_info, prim_info);
