@@ -446,8 +446,13 @@ __global__ __launch_bounds__(256) void shade_kernel(DevScene s, rt_camera cam, D
   double* __restrict__ next = w.rays[(level + 1) & 1];
   const size_t cap = w.cap_nodes;
   const uint32_t lane = threadIdx.x & 63u;
-  for (uint32_t wbase = blockIdx.x * blockDim.x + (threadIdx.x - lane); wbase < n_rays; wbase += gridDim.x * blockDim.x) {
-    uint32_t id = wbase + lane;
+#ifndef RT_HOST_EMU
+  __shared__ uint32_t sh_count[2][4], sh_base[2];  // node allocation of the 4 wavefronts of a block, double-buffered by iteration
+  uint32_t parity = 0;
+#endif
+  // (the loop is uniform over the BLOCK: its wavefronts meet at two barriers per iteration)
+  for (uint32_t bbase = blockIdx.x * blockDim.x; bbase < n_rays; bbase += gridDim.x * blockDim.x) {
+    uint32_t id = bbase + threadIdx.x;
     bool valid = id < n_rays;
     uint32_t prim = RT_NONE;
     if (valid) prim = w.hit_prim[level ? 1 : 0][id];
@@ -455,10 +460,23 @@ __global__ __launch_bounds__(256) void shade_kernel(DevScene s, rt_camera cam, D
     d3 o = mk3(0., 0., 0.), d = mk3(0., 0., 1.);
     uint32_t parent = id, root = id;  // level 0: the sample
     if (valid && level != 0) load_ray(queue, id, o, d, parent, root);
-#ifdef RT_EXP_NO_NODE_ATOMIC  // timing experiment only (wrong pixels): what the node-allocation atomic costs
-    uint32_t node = id;
-#else
+#ifdef RT_HOST_EMU
     uint32_t node = wave_take(&w.ctrl->n_nodes, hit);
+#else
+    // One atomic per block and iteration (one per wavefront cost 2.3 ms of the bench frame's 10 ms of shading); the
+    // block's 256 rays get consecutive node records, in ray order.
+    unsigned long long hm = __builtin_amdgcn_ballot_w64(hit);
+    const uint32_t wv = threadIdx.x >> 6;
+    if (lane == 0) sh_count[parity][wv] = (uint32_t)__builtin_popcountll(hm);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      uint32_t total = sh_count[parity][0] + sh_count[parity][1] + sh_count[parity][2] + sh_count[parity][3];
+      sh_base[parity] = total ? atomicAdd(&w.ctrl->n_nodes, total) : 0u;
+    }
+    __syncthreads();
+    uint32_t node = sh_base[parity] + rank_in(hm);
+    for (uint32_t k = 0; k < wv; k++) node += sh_count[parity][k];
+    parity ^= 1u;
 #endif
     if (hit && node >= w.cap_nodes) {  // no room for this hit: the whole sample goes to the fallback
       flag_sample(w, root);
