@@ -364,8 +364,7 @@ __global__ __launch_bounds__(64, RT_CLOSEST_WAVES) void trace_closest_kernel(Dev
           w.retrace[k] = my;
           my = RT_NONE;
         } else {
-          uint32_t m = s.prim_info[T.p].y;
-          if (!approx_eq(s.material[(size_t)m * RT_MAT_STRIDE + RT_MAT_TRANSPARENCY], 0.)) {
+          if (s.prim_flags[T.p] & 1u) {  // a transparent material (one byte instead of the prim_info -> material chain)
             // Intersection::compute_refractive (intersection.rs:184-190): the negative-t intersections of this ray
             ht = T.limit;
             hu = T.a;

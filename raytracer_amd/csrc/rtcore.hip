@@ -1118,6 +1118,14 @@ int rt_scene_create(const rt_scene_desc* d, rt_scene** out) {
   UP(entries, entries);
   UP(prim_info, prim_info);
   UPA(uint32_t, d->prim_csg_left, d->n_prims, prim_csg_left);
+  {
+    std::vector<uint8_t> flags(d->n_prims, 0);
+    for (uint32_t i = 0; i < d->n_prims; i++) {
+      double tr = d->material[(size_t)d->prim_material[i] * RT_MAT_STRIDE + RT_MAT_TRANSPARENCY];
+      if (!(tr == 0. || std::fabs(tr - 0.) < 1.0e-8)) flags[i] = 1;  // !approx_eq(transparency, 0) (approx_eq.rs:16-20)
+    }
+    UP(flags, prim_flags);
+  }
   UPA(double, d->xform_inv, (size_t)d->n_xforms * 16, xform_inv);
   UP(tri_isect, tri_isect);
   UP(tri_norm, tri_norm);
