@@ -238,10 +238,16 @@ __device__ __forceinline__ float key_below(double t) {
 }
 
 __device__ __forceinline__ void stack_push(Trav& T, uint2* lds, uint2* ovf, uint32_t ref, float t_rd, Counters& cnt) {
-  uint2 e = make_uint2(ref, __float_as_uint(t_rd));
-  if (T.sp < RT_LDS_STACK) lds[T.sp * 64] = e;
-  else ovf[min(T.sp - RT_LDS_STACK, RT_OVF_STACK - 1)] = e;  // cannot run over: rt_scene_create rejects a tree that needs more than
-  T.sp++;                                                     // RT_FAST_STACK_MAX entries (the clamp only keeps a bug inside the array)
+  // (the two branches store differently shaped values on purpose: identical stores get merged into one FLAT store through
+  // a selected pointer, which takes the slow path through both the LDS and the memory pipeline — on every push)
+  if (T.sp < RT_LDS_STACK) {
+    *reinterpret_cast<unsigned long long*>(&lds[T.sp * 64]) = (unsigned long long)ref | ((unsigned long long)__float_as_uint(t_rd) << 32);
+  } else {
+    int i = min(T.sp - RT_LDS_STACK, RT_OVF_STACK - 1);  // cannot run over: rt_scene_create rejects a tree that needs more
+    ovf[i].x = ref;                                       // than RT_FAST_STACK_MAX entries (the clamp only keeps a bug inside
+    ovf[i].y = __float_as_uint(t_rd);                     // the array)
+  }
+  T.sp++;
 }
 
 __device__ __forceinline__ uint32_t stack_pop(Trav& T, const uint2* lds, const uint2* ovf) {
