@@ -460,7 +460,8 @@ int rts_flatten(void* vb, double animate_time, int build_bvh, rt_scene_desc* out
   FlatScene& f = b->flat;
   b->frame_root = b->root->clone();
   if (animate_time == animate_time) b->frame_root->group_animate(animate_time);
-  if (build_bvh) b->frame_root->build_bvh();
+  if (build_bvh == 2) b->frame_root->build_bvh_plain();
+  else if (build_bvh) b->frame_root->build_bvh();
   std::vector<const Object*> chain;
   uint32_t root_idx;
   if (!flatten_group(f, *b->frame_root, chain, root_idx)) return -1;

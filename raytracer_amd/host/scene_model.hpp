@@ -155,7 +155,8 @@ struct Object {
   void local_transform(const std::vector<LocalTransformation>& ls);  // local_transform.rs:15-20
   void set_material(const Material& m);                        // object.rs:233-239
   void add_child(ObjectPtr child);                             // group.rs:76-80
-  void build_bvh();                                            // group.rs:144-167
+  void build_bvh();                                            // group.rs:144-167 (compact-array form)
+  void build_bvh_plain();                                      // the same, as the reference writes it (cross-check)
   void into_group_with_bbox(const Material& m);                // object.rs:169-179
   void animate(double time);                                   // object.rs:108-121
   void group_animate(double time);                             // group.rs:236-241

@@ -139,6 +139,37 @@ def test_bvh_build_dragon_counts():
     assert len(prim_refs) == d.n_prims and len(np.unique(prim_refs)) == d.n_prims
 
 
+def _tables(flat):
+    d = flat.desc
+    out = {"counts": tuple(getattr(d, f) for f, _ in N.rt_scene_desc._fields_ if f.startswith("n_"))}
+    for f, _ in N.rt_scene_desc._fields_:
+        if not f.startswith("n_") and f != "abi_version" and getattr(d, f):
+            out[f] = flat.array(f).tobytes()
+    return out
+
+
+@pytest.mark.parametrize("rel, time", [
+    ("images/general/dragons.yml", None),            # 6 meshes, cylinders, cubes, planes (unbounded boxes: NaN candidates)
+    ("images/general/local-transforms.yml", None),
+    ("images/general/cover.yml", None),              # many analytic primitives in nested groups
+    ("images/chapters/groups.yml", None),
+    ("animations/general/csg-lens.yml", 0.4),        # CSG children
+    ("animations/general/rotating-dragon.yml", 0.7),  # an animated mesh: every triangle moves, the tree is rebuilt
+])
+def test_compact_bvh_builder_builds_the_reference_tree(rel, time):
+    """build_bvh (one scoring pass over a compact array, scene_model.cpp) against build_bvh_plain (group.rs:87-167
+    as the reference writes it: 15 passes over the children): every flattened table byte for byte."""
+    path = os.path.join(GOLDEN, "scenes", rel)
+    if not os.path.exists(path):
+        pytest.skip(f"{rel} is not among the committed scenes")
+    rs = Y.load_scene(path)
+    fast = _tables(rs.builder.flatten(time=time, build_bvh=True))
+    plain = _tables(rs.builder.flatten(time=time, build_bvh=2))
+    assert fast.keys() == plain.keys()
+    for k in fast:
+        assert fast[k] == plain[k], k
+
+
 def test_group_bbox_is_transformed_not_recomputed():  # group.rs:263-270: the group's own box goes through 8 corners
     sb = S.SceneBuilder()
     g = sb.group([sb.primitive(N.SPHERE)])
