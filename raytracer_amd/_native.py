@@ -82,6 +82,15 @@ def _load(name: str) -> C.CDLL:
     if not os.path.exists(path):
         raise RuntimeError(
             f"{path} is missing: build the native libraries first (python -c 'import __graft_entry__ as g; g.build()')")
+    if name == "librtcore.so":
+        # One HIP runtime per process.  PyTorch ships its own libamdhip64/libhsa-runtime64; librtcore.so links the
+        # system one under the same soname.  Whichever is loaded first serves both, but if the system copy comes first
+        # torch later brings a second HSA runtime and then finds no GPU.  torch is the plumbing for device buffers and
+        # streams in every GPU caller of this package, so load it (not initialise it) first when it is installed.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
     return C.CDLL(path)
 
 
@@ -125,6 +134,8 @@ def scene_lib() -> C.CDLL:
     L.rts_matrix_mul.argtypes = [_pd, _pd, _pd]
     L.rts_camera.argtypes = [C.c_uint32, C.c_uint32, C.c_double, _pd, C.POINTER(rt_camera)]
     L.rts_flatten.argtypes = [C.c_void_p, C.c_double, C.c_int, C.POINTER(rt_scene_desc)]
+    L.rts_flatten_frame.argtypes = [C.c_void_p, C.c_double, C.c_int, C.POINTER(C.c_void_p), C.POINTER(rt_scene_desc)]
+    L.rts_frame_free.argtypes = [C.c_void_p]
     _scene_lib = L
     return L
 

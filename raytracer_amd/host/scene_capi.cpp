@@ -454,17 +454,49 @@ int rts_camera(uint32_t width, uint32_t height, double fov, const double* view16
 // Flattens the scene.  animate_time: NaN -> Renderer::render path (compute_bvh on the scene itself,
 // renderer.rs:77); otherwise the AnimationRenderer::render_frame path (scene.animate(time), scene.rs:30-36).
 // The returned tables stay valid until the next rts_flatten / rts_free on this builder.
+static int flatten_frame(const Builder* b, double animate_time, int build_bvh, FlatScene& f, ObjectPtr& frame_root,
+                         rt_scene_desc* out);
+
 int rts_flatten(void* vb, double animate_time, int build_bvh, rt_scene_desc* out) {
   Builder* b = (Builder*)vb;
   b->flat = FlatScene();
-  FlatScene& f = b->flat;
-  b->frame_root = b->root->clone();
-  if (animate_time == animate_time) b->frame_root->group_animate(animate_time);
-  if (build_bvh == 2) b->frame_root->build_bvh_plain();
-  else if (build_bvh) b->frame_root->build_bvh();
+  return flatten_frame(b, animate_time, build_bvh, b->flat, b->frame_root, out);
+}
+
+// One frame of an animation prepared on its own: Scene::animate (scene.rs:30-36: clone, animate, compute_bvh) + the
+// flattening, into tables owned by the returned frame object.  The builder is only read, so several threads may
+// prepare different frames of one builder at the same time (the frames of `animate` are independent,
+// animation_renderer.rs:61-66); rts_flatten, which keeps its tables in the builder, may not run concurrently.
+struct Frame {
+  FlatScene flat;
+  ObjectPtr root;
+};
+int rts_flatten_frame(void* vb, double animate_time, int build_bvh, void** frame_out, rt_scene_desc* out) {
+  Frame* fr = new Frame();
+  int rc = flatten_frame((const Builder*)vb, animate_time, build_bvh, fr->flat, fr->root, out);
+  if (rc != 0) {
+    delete fr;
+    fr = nullptr;
+  } else {
+    // the tables are copies: release the object tree and the flattening scratch here, on the thread that built them
+    fr->root.reset();
+    std::vector<std::vector<uint32_t>>().swap(fr->flat.node_children);
+    fr->flat.material_index.clear();
+  }
+  *frame_out = fr;
+  return rc;
+}
+void rts_frame_free(void* frame) { delete (Frame*)frame; }
+
+static int flatten_frame(const Builder* b, double animate_time, int build_bvh, FlatScene& f, ObjectPtr& frame_root,
+                         rt_scene_desc* out) {
+  frame_root = b->root->clone();
+  if (animate_time == animate_time) frame_root->group_animate(animate_time);
+  if (build_bvh == 2) frame_root->build_bvh_plain();
+  else if (build_bvh) frame_root->build_bvh();
   std::vector<const Object*> chain;
   uint32_t root_idx;
-  if (!flatten_group(f, *b->frame_root, chain, root_idx)) return -1;
+  if (!flatten_group(f, *frame_root, chain, root_idx)) return -1;
   f.node_child_begin.push_back(0);
   for (auto& v : f.node_children) {
     f.child_ref.insert(f.child_ref.end(), v.begin(), v.end());

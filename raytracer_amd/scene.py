@@ -222,6 +222,19 @@ class FlatScene:
         return np.ctypeslib.as_array(ptr, shape=(count,)).reshape(shape).copy()
 
 
+class _FrameTables:
+    """Owner of one rts_flatten_frame result; keeps the builder alive too."""
+
+    def __init__(self, builder: "SceneBuilder", frame):
+        self._builder = builder
+        self._frame = frame
+
+    def __del__(self):
+        if self._frame:
+            self._builder._L.rts_frame_free(self._frame)
+            self._frame = None
+
+
 class SceneBuilder:
     """`SceneBuilder` (scene.rs:57-147) over an arena of object handles."""
 
@@ -308,6 +321,14 @@ class SceneBuilder:
         t = float("nan") if time is None else float(time)
         self._check(self._L.rts_flatten(self._b, t, int(build_bvh), C.byref(desc)))
         return FlatScene(desc, self)
+
+    def flatten_frame(self, time: float, build_bvh: bool = True) -> FlatScene:
+        """One animation frame (Scene::animate(t), scene.rs:30-36) into tables of its own.  Unlike `flatten` this only
+        reads the builder, so worker threads may prepare several frames at once (the native call drops the GIL)."""
+        desc = N.rt_scene_desc()
+        frame = C.c_void_p()
+        self._check(self._L.rts_flatten_frame(self._b, float(time), int(build_bvh), C.byref(frame), C.byref(desc)))
+        return FlatScene(desc, _FrameTables(self, frame))
 
 
 def make_camera(width: int, height: int, fov: float, view=IDENTITY) -> N.rt_camera:

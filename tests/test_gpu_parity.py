@@ -71,6 +71,29 @@ def test_animation_frames_vs_oracle(name, time):
     check_against_oracle(rs.builder.flatten(time=time), rs.camera, rs.options())
 
 
+def test_animation_driver_frames_in_order_and_equal_to_single_frames():
+    """AnimationRenderer::render_animation (animation_renderer.rs:109-122): frames prepared ahead on worker threads,
+    rendered and quantised on the device, handed over in index order; each equals the frame rendered on its own
+    (render_frame, :61-66), which is checked against the oracle."""
+    from raytracer_amd.animation import AnimationRenderer
+    rs = Y.load_scene(scene_path("animations", "general/sphere"), width=100, height=100)
+    anim = AnimationRenderer(rs, 12, 0.5)
+    got = []
+    anim.render_animation(lambda i, img: got.append((i, img)), prep_workers=3)
+    assert [i for i, _ in got] == list(range(6)) and anim.timings["frames"] == 6
+    for i, img in got:
+        assert img.dtype == np.uint8 and img.shape == (100, 100, 3)
+        f64 = anim.render_frame(anim.frame_time(i))
+        assert np.array_equal(img, O.quantize(f64))
+        if i in (0, 3):
+            check_against_oracle(rs.builder.flatten(time=anim.frame_time(i)), rs.camera, rs.options(), gpu=f64)
+    assert not np.array_equal(got[0][1], got[3][1])  # the sphere moved
+    # two ranks: frame i belongs to rank i % 2, no exchange
+    odd = []
+    anim.render_animation(lambda i, img: odd.append(i), rank=1, world=2, prep_workers=2)
+    assert odd == [1, 3, 5]
+
+
 def test_readme_scene_config1():
     rs = Y.load_scene(os.path.join(os.path.dirname(GOLDEN), "..", "scenes", "readme.yml"), depth=5, supersampling_level=2)
     check_against_oracle(rs.builder.flatten(), rs.camera, rs.options())

@@ -198,3 +198,23 @@ def test_animation_cycle_and_frame_zero():
     assert f0.desc.n_xforms == 0 and f1.desc.n_xforms == 1
     # linear timing, translate (0,2,0) over 0.5 s: at t = 0.25 the sphere is 1 up -> inverse has -1 in the y translation
     assert np.allclose(f1.array("xform_inv")[0].reshape(4, 4)[1, 3], -1.)
+
+
+def test_frame_count_and_duration():  # animation_renderer.rs:233-242
+    from raytracer_amd.animation import AnimationRenderer, frame_count
+    assert frame_count(24, 10.0) == 240 and frame_count(30, 0.5) == 15
+    assert frame_count(60, 1.0) == 60 and frame_count(3, 0.5) == 2  # 1.5 rounds away from zero
+    a = AnimationRenderer(None, 24, 10.0)
+    assert abs(a.frame_duration() - 1. / 24.) < 1e-8 and a.frame_time(6) == 6 * (1. / 24.)
+
+
+def test_frames_prepared_on_threads_equal_frames_prepared_one_by_one():
+    """rts_flatten_frame only reads the builder: frames prepared concurrently (the animation driver's worker pool) are
+    the tables rts_flatten gives for the same time."""
+    from concurrent.futures import ThreadPoolExecutor
+    rs = Y.load_scene(os.path.join(GOLDEN, "scenes", "animations", "general", "csg-lens.yml"))
+    times = [i / 20. for i in range(12)]
+    with ThreadPoolExecutor(4) as pool:
+        frames = list(pool.map(rs.builder.flatten_frame, times))
+    for t, fr in zip(times, frames):
+        assert _tables(fr) == _tables(rs.builder.flatten(time=t))
