@@ -338,6 +338,8 @@ struct FastLayout {
   std::vector<uint32_t> prim_tri;  // triangle primitives: slot in the device triangle tables (leaf order), else RT_NONE
   uint32_t n_dev_tris = 0;
   uint32_t depth = 0;
+  uint32_t leaf_tris = 4;      // all-triangle subtrees of at most this many triangles are one leaf (<= 2: the reference's
+                               // leaves; 4 measured best: dragons 4K 54.5 -> 53.0 ms, dragon 800x800 4.47 -> 4.15 ms)
   std::string error;
 };
 
@@ -444,6 +446,23 @@ uint32_t fold_items(FastLayout& L, const std::vector<FastItem>& items, size_t fr
   return RT_MAKE_FREF(RT_FREF_INNER, 0, id);
 }
 
+// Collects the primitives below group `g` (in the reference's child order) if they are at most `limit` plain triangles.
+bool small_triangle_subtree(const rt_scene_desc* d, const FastLayout& L, uint32_t g, uint32_t limit, std::vector<uint32_t>& out) {
+  uint32_t b = d->node_child_begin[g], e = d->node_child_begin[g + 1];
+  for (uint32_t i = b; i < e; i++) {
+    uint32_t ref = d->child_ref[i], kind = ref >> RT_REF_KIND_SHIFT, idx = ref & RT_REF_INDEX_MASK;
+    if (kind == RT_REF_NODE) {
+      if (!small_triangle_subtree(d, L, idx, limit, out)) return false;
+    } else if (kind == RT_REF_PRIM && is_triangle_prim(d, idx) && L.prim_tri[idx] == RT_NONE) {
+      out.push_back(ref);
+      if (out.size() > limit) return false;
+    } else {
+      return false;
+    }
+  }
+  return true;
+}
+
 // How the parent of group `g` refers to it (the box is g's own, tested by the parent).
 uint32_t build_group(const rt_scene_desc* d, FastLayout& L, uint32_t g, uint32_t depth) {
   if (depth > L.depth) L.depth = depth;
@@ -453,6 +472,14 @@ uint32_t build_group(const rt_scene_desc* d, FastLayout& L, uint32_t g, uint32_t
   }
   const double* bb = d->node_bbox + (size_t)g * 6;
   uint32_t b = d->node_child_begin[g], e = d->node_child_begin[g + 1];
+  if (L.leaf_tris > 2) {  // a small all-triangle subtree becomes ONE leaf behind the group's box
+    std::vector<uint32_t> all;
+    if (small_triangle_subtree(d, L, g, L.leaf_tris, all) && !all.empty()) {
+      std::vector<FastItem> one;
+      make_leaves(d, L, all, bb, one);
+      if (one.size() == 1) return one[0].ref;
+    }
+  }
   std::vector<uint32_t> direct, groups;
   for (uint32_t i = b; i < e; i++) {
     uint32_t ref = d->child_ref[i];
@@ -550,6 +577,7 @@ void fold_nodes(FastLayout& L) {
 bool build_fast_layout(const rt_scene_desc* d, FastLayout& L) {
   assign_ranks(d, L.prim_rank);
   L.prim_tri.assign(d->n_prims, RT_NONE);
+  if (const char* e = getenv("RT_LEAF_TRIS")) L.leaf_tris = (uint32_t)std::min(std::max(atoi(e), 1), (int)RT_FREF_LEAF_MAX);
   L.bin.reserve((size_t)d->n_nodes + 2);
   L.bin.emplace_back();  // node 0: the synthetic root
   uint32_t root = build_group(d, L, 0, 1);
