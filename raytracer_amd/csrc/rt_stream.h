@@ -436,131 +436,208 @@ __global__ __launch_bounds__(64, 2) void retrace_kernel(DevScene s, rt_camera ca
 // shade: IntersecComputations::new (intersection.rs:217-256) for every hit of the level -> node records, and the
 // reflected / refracted rays of the next level (integrator.rs:154-197).
 // ---------------------------------------------------------------------------------------------
+// One hit -> its node record and its child rays' origin/direction (shared by both loop shapes below).
+struct ShadeOut {
+  bool want_reflect, want_refract;
+  d3 child_o[2], child_d[2];
+};
 template <bool CAMERA, bool STATS>
-__global__ __launch_bounds__(256) void shade_kernel(DevScene s, rt_camera cam, DevOptions opt, Ws w, Batch b, uint32_t level,
+__device__ __forceinline__ void shade_hit(const DevScene& s, const rt_camera& cam, const DevOptions& opt, const Ws& w, const Batch& b,
+                                          uint32_t level, const double* __restrict__ queue, uint32_t id, uint32_t prim, uint32_t node,
+                                          uint32_t& root, ShadeOut& out, Counters& cnt) {
+  const size_t cap = w.cap_nodes;
+  d3 o, d;
+  uint32_t parent = id;  // level 0: the sample
+  root = id;
+  if (level == 0) first_ray<CAMERA>(cam, opt, b, id, o, d);
+  else load_ray(queue, id, o, d, parent, root);
+  const double* h = w.hit_f + id;
+  const size_t hcap = w.cap_rays;
+  double t = h[0], u = h[hcap], v = h[2 * hcap], n1 = h[3 * hcap], n2 = h[4 * hcap];
+  uint4 info = s.prim_info[prim];
+  const double* mat = s.material + (size_t)info.y * RT_MAT_STRIDE;
+  HitGeom g = hit_geom(s, info, o, d, t, u, v);
+  if (STATS) {  // algorithmic bytes of shading this hit
+    cnt.hits++;
+    uint32_t bytes = 64u + 48u * s.n_lights;
+    bytes += info.x == RT_SHAPE_SMOOTH_TRIANGLE ? 72u : (info.x == RT_SHAPE_TRIANGLE ? 24u : (info.z != RT_NONE ? 96u : 0u));
+    if (s.pattern_kind[info.y] != RT_PATTERN_CONST) bytes += 144u;
+    cnt.hit_bytes += bytes;
+  }
+  // reflected_color_at_depth (integrator.rs:154-168)
+  if (level < opt.max_depth && !approx_eq(mat[RT_MAT_REFLECTIVITY], 0.)) {
+    out.want_reflect = true;
+    out.child_o[0] = g.over;
+    out.child_d[0] = g.reflect_v;
+  }
+  // refracted_color_at_depth (integrator.rs:170-197)
+  if (level < opt.max_depth && !approx_eq(mat[RT_MAT_TRANSPARENCY], 0.)) {
+    double ratio = n1 / n2;
+    double cos_i = dot3(g.eye, g.normal);
+    double sin2_t = (ratio * ratio) * (1. - cos_i * cos_i);
+    if (!(sin2_t > 1.)) {
+      double cos_t = sqrt(1. - sin2_t);
+      out.want_refract = true;
+      out.child_o[1] = g.under;
+      out.child_d[1] = sub3(scale3(g.normal, ratio * cos_i - cos_t), scale3(g.eye, ratio));
+    }
+  }
+  double* nf = w.node_f + node;
+  nf[(NF_OVER + 0) * cap] = g.over.x;
+  nf[(NF_OVER + 1) * cap] = g.over.y;
+  nf[(NF_OVER + 2) * cap] = g.over.z;
+  nf[(NF_EYE + 0) * cap] = g.eye.x;
+  nf[(NF_EYE + 1) * cap] = g.eye.y;
+  nf[(NF_EYE + 2) * cap] = g.eye.z;
+  nf[(NF_NORMAL + 0) * cap] = g.normal.x;
+  nf[(NF_NORMAL + 1) * cap] = g.normal.y;
+  nf[(NF_NORMAL + 2) * cap] = g.normal.z;
+  nf[NF_N1 * cap] = n1;
+  nf[NF_N2 * cap] = n2;
+  // a child ray that misses returns black; the slots of children that are not traced are never read (combine_kernel)
+  if (out.want_reflect)
+    for (int k = 0; k < 3; k++) nf[(NF_REFL + k) * cap] = 0.;
+  if (out.want_refract)
+    for (int k = 0; k < 3; k++) nf[(NF_REFR + k) * cap] = 0.;
+  uint32_t* nu = w.node_u + node;
+  nu[NU_PRIM * cap] = prim | (out.want_reflect ? RT_NODE_REFLECTED : 0u) | (out.want_refract ? RT_NODE_REFRACTED : 0u);
+  nu[NU_PARENT * cap] = parent;
+  nu[NU_ROOT * cap] = root;
+}
+
+// The rays of level + 1 of one wavefront, stored from queue slot `base` on: its reflected rays first, then its refracted
+// rays (called by all its lanes; m1 / m2 = the wavefront's lanes that want each).
+template <bool STATS>
+__device__ __forceinline__ void store_children(const Ws& w, double* __restrict__ next, uint32_t base, unsigned long long m1,
+                                               unsigned long long m2, uint32_t node, uint32_t root, const ShadeOut& out, Counters& cnt) {
+  const uint32_t n1c = (uint32_t)__builtin_popcountll(m1);
+  if (out.want_reflect) {
+    uint32_t k = base + rank_in(m1);
+    if (k < w.cap_rays) {
+      store_ray(next, k, out.child_o[0], out.child_d[0], node, root);
+      if (STATS) cnt.rays_reflect++;
+    } else {
+      flag_sample(w, root);
+    }
+  }
+  if (out.want_refract) {
+    uint32_t k = base + n1c + rank_in(m2);
+    if (k < w.cap_rays) {
+      store_ray(next, k, out.child_o[1], out.child_d[1], node | RT_PARENT_REFRACT, root);
+      if (STATS) cnt.rays_refract++;
+    } else {
+      flag_sample(w, root);
+    }
+  }
+}
+
+// A block looks at RT_SHADE_SPAN rays per iteration, packs the ones that hit (in ray order) into a list in LDS, takes
+// their node records with ONE atomic, and then shades 256 hits at a time: at level 0 of the bench frame only one primary
+// ray in six hits anything, and a loop that shades "its own ray or nothing" leaves most lanes idle through every
+// dependent fetch (prim -> prim_info -> normals / material).  Node records of a span are consecutive and in ray order,
+// which is what keeps neighbouring shadow rays in one wavefront later.
+#ifndef RT_SHADE_SPAN
+#define RT_SHADE_SPAN 1024u
+#endif
+#ifndef RT_SHADE_WAVES
+#define RT_SHADE_WAVES 4
+#endif
+template <bool CAMERA, bool STATS>
+__global__ __launch_bounds__(256, RT_SHADE_WAVES) void shade_kernel(DevScene s, rt_camera cam, DevOptions opt, Ws w, Batch b, uint32_t level,
                                                     unsigned long long* stats, uint32_t* overflow_flag) {
   Counters cnt = {};
   const uint32_t n_rays = level == 0 ? b.n_samples : w.ctrl->n_rays[level];
   const double* __restrict__ queue = w.rays[level & 1];
   double* __restrict__ next = w.rays[(level + 1) & 1];
-  const size_t cap = w.cap_nodes;
-  const uint32_t lane = threadIdx.x & 63u;
-#ifndef RT_HOST_EMU
-  __shared__ uint32_t sh_count[2][4], sh_base[2];  // node allocation of the 4 wavefronts of a block, double-buffered by iteration
-  uint32_t parity = 0;
-#endif
-  // (the loop is uniform over the BLOCK: its wavefronts meet at two barriers per iteration)
-  for (uint32_t bbase = blockIdx.x * blockDim.x; bbase < n_rays; bbase += gridDim.x * blockDim.x) {
-    uint32_t id = bbase + threadIdx.x;
-    bool valid = id < n_rays;
-    uint32_t prim = RT_NONE;
-    if (valid) prim = w.hit_prim[level ? 1 : 0][id];
-    bool hit = valid && prim != RT_NONE;
-    d3 o = mk3(0., 0., 0.), d = mk3(0., 0., 1.);
-    uint32_t parent = id, root = id;  // level 0: the sample
-    if (valid && level != 0) load_ray(queue, id, o, d, parent, root);
+  const uint32_t* __restrict__ prims = w.hit_prim[level ? 1 : 0];
 #ifdef RT_HOST_EMU
-    uint32_t node = wave_take(&w.ctrl->n_nodes, hit);
-#else
-    // One atomic per block and iteration (one per wavefront cost 2.3 ms of the bench frame's 10 ms of shading); the
-    // block's 256 rays get consecutive node records, in ray order.
-    unsigned long long hm = __builtin_amdgcn_ballot_w64(hit);
-    const uint32_t wv = threadIdx.x >> 6;
-    if (lane == 0) sh_count[parity][wv] = (uint32_t)__builtin_popcountll(hm);
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      uint32_t total = sh_count[parity][0] + sh_count[parity][1] + sh_count[parity][2] + sh_count[parity][3];
-      sh_base[parity] = total ? atomicAdd(&w.ctrl->n_nodes, total) : 0u;
-    }
-    __syncthreads();
-    uint32_t node = sh_base[parity] + rank_in(hm);
-    for (uint32_t k = 0; k < wv; k++) node += sh_count[parity][k];
-    parity ^= 1u;
-#endif
-    if (hit && node >= w.cap_nodes) {  // no room for this hit: the whole sample goes to the fallback
+  // (one lane at a time: no block to cooperate with)
+  for (uint32_t id = blockIdx.x * blockDim.x + threadIdx.x; id < n_rays; id += gridDim.x * blockDim.x) {
+    uint32_t prim = prims[id];
+    if (prim == RT_NONE) continue;
+    uint32_t node = wave_take(&w.ctrl->n_nodes, true), root = id;
+    if (node >= w.cap_nodes) {  // no room for this hit: the whole sample goes to the fallback
+      if (level != 0) {
+        d3 o, d;
+        uint32_t parent;
+        load_ray(queue, id, o, d, parent, root);
+      }
       flag_sample(w, root);
-      hit = false;
+      continue;
     }
-    bool want_reflect = false, want_refract = false;
-    d3 child_o[2], child_d[2];
-    if (hit) {
-      if (level == 0) first_ray<CAMERA>(cam, opt, b, id, o, d);
-      const double* h = w.hit_f + id;
-      const size_t hcap = w.cap_rays;
-      double t = h[0], u = h[hcap], v = h[2 * hcap], n1 = h[3 * hcap], n2 = h[4 * hcap];
-      uint4 info = s.prim_info[prim];
-      const double* mat = s.material + (size_t)info.y * RT_MAT_STRIDE;
-      HitGeom g = hit_geom(s, info, o, d, t, u, v);
-      if (STATS) {  // algorithmic bytes of shading this hit
-        cnt.hits++;
-        uint32_t bytes = 64u + 48u * s.n_lights;
-        bytes += info.x == RT_SHAPE_SMOOTH_TRIANGLE ? 72u : (info.x == RT_SHAPE_TRIANGLE ? 24u : (info.z != RT_NONE ? 96u : 0u));
-        if (s.pattern_kind[info.y] != RT_PATTERN_CONST) bytes += 144u;
-        cnt.hit_bytes += bytes;
-      }
-      // reflected_color_at_depth (integrator.rs:154-168)
-      if (level < opt.max_depth && !approx_eq(mat[RT_MAT_REFLECTIVITY], 0.)) {
-        want_reflect = true;
-        child_o[0] = g.over;
-        child_d[0] = g.reflect_v;
-      }
-      // refracted_color_at_depth (integrator.rs:170-197)
-      if (level < opt.max_depth && !approx_eq(mat[RT_MAT_TRANSPARENCY], 0.)) {
-        double ratio = n1 / n2;
-        double cos_i = dot3(g.eye, g.normal);
-        double sin2_t = (ratio * ratio) * (1. - cos_i * cos_i);
-        if (!(sin2_t > 1.)) {
-          double cos_t = sqrt(1. - sin2_t);
-          want_refract = true;
-          child_o[1] = g.under;
-          child_d[1] = sub3(scale3(g.normal, ratio * cos_i - cos_t), scale3(g.eye, ratio));
-        }
-      }
-      double* nf = w.node_f + node;
-      nf[(NF_OVER + 0) * cap] = g.over.x;
-      nf[(NF_OVER + 1) * cap] = g.over.y;
-      nf[(NF_OVER + 2) * cap] = g.over.z;
-      nf[(NF_EYE + 0) * cap] = g.eye.x;
-      nf[(NF_EYE + 1) * cap] = g.eye.y;
-      nf[(NF_EYE + 2) * cap] = g.eye.z;
-      nf[(NF_NORMAL + 0) * cap] = g.normal.x;
-      nf[(NF_NORMAL + 1) * cap] = g.normal.y;
-      nf[(NF_NORMAL + 2) * cap] = g.normal.z;
-      nf[NF_N1 * cap] = n1;
-      nf[NF_N2 * cap] = n2;
-      for (int k = 0; k < 6; k++) nf[(NF_REFL + k) * cap] = 0.;  // a child ray that misses returns black
-      uint32_t* nu = w.node_u + node;
-      nu[NU_PRIM * cap] = prim | (want_reflect ? RT_NODE_REFLECTED : 0u) | (want_refract ? RT_NODE_REFRACTED : 0u);
-      nu[NU_PARENT * cap] = parent;
-      nu[NU_ROOT * cap] = root;
-    }
-    // the rays of level + 1: the wavefront's reflected rays first, then its refracted rays
-    unsigned long long m1 = __builtin_amdgcn_ballot_w64(want_reflect), m2 = __builtin_amdgcn_ballot_w64(want_refract);
-    if (want_reflect || want_refract) {
-      uint32_t n1c = (uint32_t)__builtin_popcountll(m1), total = n1c + (uint32_t)__builtin_popcountll(m2);
-      uint32_t base = 0;
-      if (rank_in(m1 | m2) == 0) base = atomicAdd(&w.ctrl->n_rays[level + 1], total);
-      base = __builtin_amdgcn_readfirstlane(base);
-      if (want_reflect) {
-        uint32_t k = base + rank_in(m1);
-        if (k < w.cap_rays) {
-          store_ray(next, k, child_o[0], child_d[0], node, root);
-          if (STATS) cnt.rays_reflect++;
-        } else {
-          flag_sample(w, root);
-        }
-      }
-      if (want_refract) {
-        uint32_t k = base + n1c + rank_in(m2);
-        if (k < w.cap_rays) {
-          store_ray(next, k, child_o[1], child_d[1], node | RT_PARENT_REFRACT, root);
-          if (STATS) cnt.rays_refract++;
-        } else {
-          flag_sample(w, root);
-        }
-      }
-    }
+    ShadeOut out = {};
+    shade_hit<CAMERA, STATS>(s, cam, opt, w, b, level, queue, id, prim, node, root, out, cnt);
+    uint32_t n_children = (out.want_reflect ? 1u : 0u) + (out.want_refract ? 1u : 0u);
+    if (n_children)
+      store_children<STATS>(w, next, atomicAdd(&w.ctrl->n_rays[level + 1], n_children), out.want_reflect ? 1ull : 0ull,
+                            out.want_refract ? 1ull : 0ull, node, root, out, cnt);
   }
+#else
+  constexpr uint32_t PER = RT_SHADE_SPAN / 256u;  // rays a thread looks at per iteration
+  __shared__ uint32_t sh_ids[RT_SHADE_SPAN];     // the span's hits: ray index within the span, in ray order
+  __shared__ uint32_t sh_count[PER * 4];          // hits of (sub-span k, wavefront wv) at [k * 4 + wv]
+  __shared__ uint32_t sh_base;
+  __shared__ uint32_t sh_children[2][4], sh_child_base[2];  // double-buffered by shading pass
+  uint32_t parity = 0;
+  const uint32_t wv = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+  // (the loop is uniform over the BLOCK: its wavefronts meet at barriers)
+  for (uint32_t bbase = blockIdx.x * RT_SHADE_SPAN; bbase < n_rays; bbase += gridDim.x * RT_SHADE_SPAN) {
+    unsigned long long hm[PER];
+    for (uint32_t k = 0; k < PER; k++) {
+      uint32_t id = bbase + k * 256u + threadIdx.x;
+      bool hit = id < n_rays && prims[id] != RT_NONE;
+      hm[k] = __builtin_amdgcn_ballot_w64(hit);
+      if (lane == 0) sh_count[k * 4 + wv] = (uint32_t)__builtin_popcountll(hm[k]);
+    }
+    __syncthreads();
+    uint32_t total = 0, before[PER];
+    for (uint32_t k = 0; k < PER; k++)
+      for (uint32_t q = 0; q < 4; q++) {
+        if (q == wv) before[k] = total;
+        total += sh_count[k * 4 + q];
+      }
+    for (uint32_t k = 0; k < PER; k++)
+      if ((hm[k] >> lane) & 1ull) sh_ids[before[k] + rank_in(hm[k])] = k * 256u + threadIdx.x;
+    if (threadIdx.x == 0) sh_base = total ? atomicAdd(&w.ctrl->n_nodes, total) : 0u;
+    __syncthreads();
+    const uint32_t base = sh_base;
+    for (uint32_t j0 = 0; j0 < total; j0 += 256u) {  // uniform over the block
+      uint32_t j = j0 + threadIdx.x;
+      bool active = j < total;
+      uint32_t node = base + j, root = 0;
+      ShadeOut out = {};
+      if (active) {
+        uint32_t id = bbase + sh_ids[j];
+        if (node >= w.cap_nodes) {  // no room for this hit: the whole sample goes to the fallback
+          root = id;
+          if (level != 0) {
+            d3 o, d;
+            uint32_t parent;
+            load_ray(queue, id, o, d, parent, root);
+          }
+          flag_sample(w, root);
+        } else {
+          shade_hit<CAMERA, STATS>(s, cam, opt, w, b, level, queue, id, prims[id], node, root, out, cnt);
+        }
+      }
+      // queue slots of the block's child rays: one atomic per 256 hits (one per wavefront was a third more shade time:
+      // every one of them goes to the same address), wavefront after wavefront
+      unsigned long long m1 = __builtin_amdgcn_ballot_w64(out.want_reflect), m2 = __builtin_amdgcn_ballot_w64(out.want_refract);
+      if (lane == 0) sh_children[parity][wv] = (uint32_t)(__builtin_popcountll(m1) + __builtin_popcountll(m2));
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        uint32_t all = sh_children[parity][0] + sh_children[parity][1] + sh_children[parity][2] + sh_children[parity][3];
+        sh_child_base[parity] = all ? atomicAdd(&w.ctrl->n_rays[level + 1], all) : 0u;
+      }
+      __syncthreads();
+      uint32_t cbase = sh_child_base[parity];
+      for (uint32_t q = 0; q < wv; q++) cbase += sh_children[parity][q];
+      parity ^= 1u;
+      store_children<STATS>(w, next, cbase, m1, m2, node, root, out, cnt);
+    }
+    __syncthreads();  // sh_ids / sh_count / sh_base are rewritten by the next iteration
+  }
+#endif
   flush_counters<STATS>(cnt, stats, overflow_flag);
 }
 
