@@ -532,13 +532,13 @@ __device__ __forceinline__ void store_children(const Ws& w, double* __restrict__
 }
 
 // A block looks at RT_SHADE_SPAN rays per iteration, packs the ones that hit (in ray order) into a list in LDS, takes
-// their node records with ONE atomic, and then shades 256 hits at a time: at level 0 of the bench frame only one primary
-// ray in six hits anything, and a loop that shades "its own ray or nothing" leaves most lanes idle through every
-// dependent fetch (prim -> prim_info -> normals / material).  Node records of a span are consecutive and in ray order,
-// which is what keeps neighbouring shadow rays in one wavefront later.
+// their node records with ONE atomic, and then shades 256 hits at a time, again with one atomic per pass for the queue
+// slots of their child rays.  Atomics on one address complete one after the other (about 9 ns each here): with one per
+// wavefront for the nodes and one for the children they were more than half of the kernel's time.  Node records of a
+// span are consecutive and in ray order, which keeps neighbouring shadow rays in one wavefront later.
 #ifndef RT_SHADE_SPAN
-#define RT_SHADE_SPAN 1024u
-#endif
+#define RT_SHADE_SPAN 256u  // 256 .. 2048 shade equally fast; a small frame's shadow rays are 20 % faster behind 256 (its
+#endif                      // node records then interleave image regions finely, which balances the shadow kernel's grabs)
 #ifndef RT_SHADE_WAVES
 #define RT_SHADE_WAVES 4
 #endif
