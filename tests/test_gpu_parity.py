@@ -390,6 +390,22 @@ def test_small_batches_and_overflow_fallback(monkeypatch):
     assert np.array_equal(out.cpu().numpy(), want)
 
 
+@pytest.mark.parametrize("name", ["images/general/dragons", "animations/general/rotating-dragon"])
+def test_leaf_size_does_not_change_pixels(monkeypatch, name):
+    """rt_scene_create merges all-triangle subtrees of up to RT_LEAF_TRIS (default 4) triangles into one leaf run.  The
+    candidate set of a ray only grows with the leaf size and the winner is decided by exact tests and visit ranks, so the
+    image is the same for the reference's own leaves (<= 2), the default and the largest run (63) — and equals the
+    reference-order render, which does not use the folded tree at all."""
+    rs = Y.load_scene(scene_path(*name.split("/", 1)), width=200, height=160, depth=5, supersampling_level=2)
+    flat, cam, opt = rs.builder.flatten(), rs.camera, rs.options()
+    want, _ = R.render(flat, cam, _ref_order(opt))
+    for leaf in ("2", "4", "63"):
+        monkeypatch.setenv("RT_LEAF_TRIS", leaf)
+        got, st = R.render(flat, cam, opt)
+        assert np.array_equal(got, want), leaf
+        assert st["fallback_flags"] == 0
+
+
 def test_timing_mode_reports_kernel_classes():
     torch = _torch()
     rs = Y.load_scene(scene_path("images", "general/cover"), width=256, height=256, depth=5, supersampling_level=2)
