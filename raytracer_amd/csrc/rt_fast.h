@@ -237,6 +237,15 @@ __device__ __forceinline__ float key_below(double t) {
   return fminf(fmaf(-fabsf(k), 1.1920929e-07f, k), 3.4028234e38f);
 }
 
+// Coordinate k of child c's box in a node fetched as 32-bit words.
+__device__ __forceinline__ double node_box_value(const uint32_t* raw, int c, int k) {
+#if RT_NODE_F64
+  return __longlong_as_double((long long)(((unsigned long long)raw[2 * (6 * c + k) + 1] << 32) | raw[2 * (6 * c + k)]));
+#else
+  return (double)__uint_as_float(raw[6 * c + k]);
+#endif
+}
+
 __device__ __forceinline__ void stack_push(Trav& T, uint2* lds, uint2* ovf, uint32_t ref, float t_rd, Counters& cnt) {
   // (the two branches store differently shaped values on purpose: identical stores get merged into one FLAT store through
   // a selected pointer, which takes the slow path through both the LDS and the memory pipeline — on every push)
@@ -303,7 +312,7 @@ __device__ __forceinline__ void trav_run(const DevScene& s, Trav& T, uint2* lds,
       // The whole node is fetched first (16-B loads, all in flight together), then tested: written out by hand because
       // the compiler otherwise fetches and waits box by box.
       const uint4* np = reinterpret_cast<const uint4*>(s.nodes + (T.cur & RT_FREF_INDEX_MASK));
-      constexpr int NQ = (RT_NODE_WIDTH * 7 + 3) / 4;
+      constexpr int NQ = RT_NODE_F64 ? (RT_NODE_WIDTH * 13 + 3) / 4 : (RT_NODE_WIDTH * 7 + 3) / 4;
       uint4 q[NQ];
       for (int k = 0; k < NQ; k++) q[k] = np[k];
       uint32_t raw[NQ * 4];
@@ -325,18 +334,18 @@ __device__ __forceinline__ void trav_run(const DevScene& s, Trav& T, uint2* lds,
       if (__builtin_amdgcn_ballot_w64(T.odd != 0u) == 0ull) {  // wave-uniform: a real branch
         for (int c = 0; c < RT_NODE_WIDTH; c++) {
           double bb[6];
-          for (int k = 0; k < 6; k++) bb[k] = (double)__uint_as_float(raw[6 * c + k]);
+          for (int k = 0; k < 6; k++) bb[k] = node_box_value(raw, c, k);
           hit[c] = box_times_finite(bb, T.o, T.dinv, tmin[c], tmax[c]);
         }
       } else {  // some lane's ray is parallel to an axis: the reference's operand order decides what 0 * inf does
         for (int c = 0; c < RT_NODE_WIDTH; c++) {
           double bb[6];
-          for (int k = 0; k < 6; k++) bb[k] = (double)__uint_as_float(raw[6 * c + k]);
+          for (int k = 0; k < 6; k++) bb[k] = node_box_value(raw, c, k);
           hit[c] = box_times(bb, T.o, T.dinv, tmin[c], tmax[c]);
         }
       }
       for (int c = 0; c < RT_NODE_WIDTH; c++) {
-        ref[c] = raw[6 * RT_NODE_WIDTH + c];
+        ref[c] = raw[(RT_NODE_F64 ? 12 : 6) * RT_NODE_WIDTH + c];
         // (& and |, not && and ||: four straight-line selects instead of four branches)
         bool h = hit[c] & !(tmin[c] > lim) & (ref[c] != RT_FREF_NONE) & (all_t | !(tmax[c] < 0.));
         if (STATS && ref[c] != RT_FREF_NONE) cnt.node_visits++;
