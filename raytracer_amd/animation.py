@@ -77,7 +77,10 @@ class AnimationRenderer:
         d_u8 = torch.empty((h, w, 3), dtype=torch.uint8, device="cuda")
         t = {"prepare_host": 0., "upload": 0., "render": 0., "readback": 0.}
 
+        device = torch.cuda.current_device()
+
         def prepare(i: int):  # worker thread: host preparation, then the upload (rt_scene_create)
+            torch.cuda.set_device(device)  # HIP's current device is per thread: upload where the render thread renders
             t0 = _time.perf_counter()
             flat = self.setup.builder.flatten_frame(self.frame_time(i))
             t1 = _time.perf_counter()
