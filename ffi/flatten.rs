@@ -104,7 +104,7 @@ impl FlatScene {
                 self.csg_depth.push(chain.len() as u8);
                 self.csg_left.push(0);
                 self.csg_right.push(0);
-                chain.push(csg);
+                chain.push(csg.as_ref());
                 let l = self.object(&csg.left, chain); // csg.rs:69-74 (pub fields)
                 let r = self.object(&csg.right, chain);
                 chain.pop();
@@ -140,7 +140,8 @@ impl FlatScene {
             Shape::Bbox => (7, false),
         };
         self.prim_shape.push(tag);
-        self.prim_material.push(self.material_id(p.material())); // object.rs:441
+        let material = self.material_id(p.material()); // object.rs:441
+        self.prim_material.push(material);
         let inv = matrix16(&p.transformation_inverse()); // object.rs:409-411 (None reads as the identity)
         if is_tri || inv.iter().zip(IDENTITY.iter()).all(|(a, b)| a.to_bits() == b.to_bits()) {
             self.prim_xform.push(RT_NONE);
