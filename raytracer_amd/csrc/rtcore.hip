@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstring>
 #include <algorithm>
+#include <mutex>
 #include <string>
 #include <utility>
 #include <vector>
@@ -235,20 +236,113 @@ int fail(int code, const std::string& msg) {
       return fail(RT_ERR_DEVICE, std::string(#expr) + " failed: " + hipGetErrorString(_e));        \
   } while (0)
 
-struct DeviceBuffers {
-  std::vector<void*> ptrs;
-  ~DeviceBuffers() {
-    for (void* p : ptrs)
-      if (p) (void)hipFree(p);
+// Device memory that scenes hand back when they are destroyed, kept for the next scene on the same device: an
+// animation creates and destroys one rt_scene per frame (a scene table arena and a render workspace each), and
+// hipMalloc / hipFree cost milliseconds and synchronise the device.  Bounded: at most 24 blocks and 96 GiB
+// (RT_POOL_MAX_BYTES); the oldest blocks go first.  rt_release_cached_memory() empties it.
+struct DevicePool {
+  struct Block {
+    void* p;
+    size_t cap;
+    int device;
+  };
+  std::mutex mu;
+  std::vector<Block> blocks;  // oldest first
+  size_t cached = 0;
+
+  // A block of at least `need` bytes on `device`: a cached one that is not more than twice too large, else a new one.
+  void* take(size_t need, int device, size_t* cap) {
+    {
+      std::lock_guard<std::mutex> lock(mu);
+      int best = -1;
+      for (size_t i = 0; i < blocks.size(); i++) {
+        const Block& b = blocks[i];
+        if (b.device != device || b.cap < need || b.cap > 2 * need + (1u << 20)) continue;
+        if (best < 0 || b.cap < blocks[(size_t)best].cap) best = (int)i;
+      }
+      if (best >= 0) {
+        Block b = blocks[(size_t)best];
+        blocks.erase(blocks.begin() + best);
+        cached -= b.cap;
+        *cap = b.cap;
+        return b.p;
+      }
+    }
+    void* p = nullptr;
+    if (hipMalloc(&p, need) != hipSuccess) {
+      (void)hipGetLastError();
+      clear();  // make room and try once more
+      if (hipMalloc(&p, need) != hipSuccess) return nullptr;
+    }
+    *cap = need;
+    return p;
+  }
+  // The caller has made sure that no GPU work still uses the block.
+  void give(void* p, size_t cap, int device) {
+    if (!p) return;
+    size_t limit = 96ull << 30;
+    if (const char* e = std::getenv("RT_POOL_MAX_BYTES")) limit = std::strtoull(e, nullptr, 10);
+    std::vector<Block> evict;
+    {
+      std::lock_guard<std::mutex> lock(mu);
+      blocks.push_back({p, cap, device});
+      cached += cap;
+      while (!blocks.empty() && (blocks.size() > 24 || cached > limit)) {
+        evict.push_back(blocks.front());
+        cached -= blocks.front().cap;
+        blocks.erase(blocks.begin());
+      }
+    }
+    for (const Block& b : evict) (void)hipFree(b.p);
+  }
+  void clear() {
+    std::vector<Block> all;
+    {
+      std::lock_guard<std::mutex> lock(mu);
+      all.swap(blocks);
+      cached = 0;
+    }
+    for (const Block& b : all) (void)hipFree(b.p);
   }
 };
+DevicePool g_device_pool;
+
+// 16-byte slots of pinned host memory (the per-frame fallback count lands in one): pinning is slow, so slots are cut from
+// 4-KiB chunks and reused; the chunks live as long as the process.
+struct PinnedSlots {
+  std::mutex mu;
+  std::vector<uint32_t*> free_slots;
+  uint32_t* take() {
+    std::lock_guard<std::mutex> lock(mu);
+    if (free_slots.empty()) {
+      void* chunk = nullptr;
+      if (hipHostMalloc(&chunk, 4096, hipHostMallocPortable) != hipSuccess) return nullptr;
+      for (size_t off = 0; off < 4096; off += 16) free_slots.push_back((uint32_t*)((char*)chunk + off));
+    }
+    uint32_t* s = free_slots.back();
+    free_slots.pop_back();
+    return s;
+  }
+  void give(uint32_t* s) {
+    if (!s) return;
+    std::lock_guard<std::mutex> lock(mu);
+    free_slots.push_back(s);
+  }
+};
+PinnedSlots g_pinned_slots;
 
 }  // namespace
 
 struct rt_scene {
   DevScene dev;
-  DeviceBuffers bufs;
+  // every scene table, the statistics counters and the summary word live in ONE device block (rt_scene_create)
+  void* arena = nullptr;
+  size_t arena_cap = 0;
+  std::vector<char> stage;                         // while rt_scene_create runs: the arena's contents on the host
+  std::vector<std::pair<size_t, void*>> fixups;    // (offset in the arena, address of the device pointer to set)
   int device = 0;
+  mutable hipEvent_t done_event = nullptr;  // recorded after every render: what the destructor waits for
+  mutable bool rendered = false;
   unsigned long long* d_stats = nullptr;  // RT_N_COUNTERS counters
   uint32_t* d_overflow = nullptr;
   size_t bytes = 0;
@@ -272,25 +366,52 @@ struct rt_scene {
   mutable std::vector<hipEvent_t> event_pool;
   mutable std::vector<int> timed_class;  // class of the i-th timed launch (events 2i, 2i+1 of the pool)
   ~rt_scene() {
-    if (ws_base) (void)hipFree(ws_base);
-    if (d_summary) (void)hipFree(d_summary);
-    if (h_summary) (void)hipHostFree(h_summary);
+    // the blocks go back to the pool, for other scenes to use at once: first wait for this scene's own GPU work
+    if (rendered && done_event) (void)hipEventSynchronize(done_event);
+    if (summary_pending && summary_event) (void)hipEventSynchronize(summary_event);
+    g_device_pool.give(ws_base, ws_bytes, device);
+    g_device_pool.give(arena, arena_cap, device);
+    g_pinned_slots.give(h_summary);
     if (summary_event) (void)hipEventDestroy(summary_event);
+    if (done_event) (void)hipEventDestroy(done_event);
     for (hipEvent_t e : event_pool) (void)hipEventDestroy(e);
   }
 };
 
 namespace {
 
+// Adds a table to the scene's arena image; the device pointer is set by commit_arena.
+size_t stage_bytes(rt_scene* sc, const void* data, size_t bytes, void* pointer_to_set) {
+  size_t off = (sc->stage.size() + 255) & ~(size_t)255;
+  sc->stage.resize(off + std::max<size_t>(bytes, 16), 0);
+  if (bytes && data) std::memcpy(sc->stage.data() + off, data, bytes);  // no data: zeros
+  sc->fixups.push_back({off, pointer_to_set});
+  sc->bytes += bytes;
+  return off;
+}
 template <class T>
 int upload(rt_scene* sc, const std::vector<T>& host, const T** out) {
-  size_t bytes = host.size() * sizeof(T);
-  void* p = nullptr;
-  HIP_TRY(hipMalloc(&p, bytes ? bytes : 16));
-  sc->bufs.ptrs.push_back(p);
-  if (bytes) HIP_TRY(hipMemcpy(p, host.data(), bytes, hipMemcpyHostToDevice));
-  sc->bytes += bytes;
-  *out = (const T*)p;
+  stage_bytes(sc, host.data(), host.size() * sizeof(T), (void*)out);
+  return RT_OK;
+}
+// One device block for everything staged, one copy (on a stream of its own: a copy on the null stream would wait for, and
+// hold up, renders of other scenes that other threads have in flight).
+int commit_arena(rt_scene* sc) {
+  size_t need = (sc->stage.size() + 255) & ~(size_t)255;
+  sc->arena = g_device_pool.take(need, sc->device, &sc->arena_cap);
+  if (!sc->arena) return fail(RT_ERR_DEVICE, "hipMalloc of the scene tables (" + std::to_string(need >> 20) + " MiB) failed");
+  hipStream_t up = nullptr;
+  HIP_TRY(hipStreamCreateWithFlags(&up, hipStreamNonBlocking));
+  hipError_t e = hipMemcpyAsync(sc->arena, sc->stage.data(), sc->stage.size(), hipMemcpyHostToDevice, up);
+  if (e == hipSuccess) e = hipStreamSynchronize(up);
+  (void)hipStreamDestroy(up);
+  if (e != hipSuccess) return fail(RT_ERR_DEVICE, std::string("upload of the scene tables failed: ") + hipGetErrorString(e));
+  for (auto& f : sc->fixups) {
+    void* p = (char*)sc->arena + f.first;
+    std::memcpy(f.second, &p, sizeof(p));
+  }
+  std::vector<char>().swap(sc->stage);
+  sc->fixups.clear();
   return RT_OK;
 }
 
@@ -749,9 +870,9 @@ void absorb_summary(const rt_scene* sc) {
 // persistent kernel has a fixed cost, 2 batches per 4K frame measured 5 % faster than 4), and the workspace
 // never takes more than a third of the device's free memory.
 int ensure_workspace(const rt_scene* sc, uint64_t want_samples, uint32_t* batch_samples) {
-  if (!sc->d_summary) {
-    if (hipMalloc((void**)&sc->d_summary, 16) != hipSuccess || hipMemset(sc->d_summary, 0, 16) != hipSuccess ||
-        hipHostMalloc((void**)&sc->h_summary, 16) != hipSuccess || hipEventCreate(&sc->summary_event) != hipSuccess)
+  if (!sc->h_summary) {  // (d_summary is part of the scene's arena, zeroed)
+    sc->h_summary = g_pinned_slots.take();
+    if (!sc->h_summary || hipEventCreate(&sc->summary_event) != hipSuccess)
       return fail(RT_ERR_DEVICE, "allocation of the frame summary failed");
     sc->h_summary[0] = 0;
   }
@@ -769,6 +890,10 @@ int ensure_workspace(const rt_scene* sc, uint64_t want_samples, uint32_t* batch_
   if (need > sc->ws_bytes) {
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b > 0) {
+      if (need > free_b / 3 + sc->ws_bytes && g_device_pool.cached) {  // cached blocks of destroyed scenes count as used
+        g_device_pool.clear();
+        (void)hipMemGetInfo(&free_b, &total_b);
+      }
       size_t budget = free_b / 3 + sc->ws_bytes;
       while (need > budget && n > 4096) {
         n = align_up(n / 2, 64);
@@ -779,16 +904,16 @@ int ensure_workspace(const rt_scene* sc, uint64_t want_samples, uint32_t* batch_
   }
   if (need > sc->ws_bytes) {
     if (sc->ws_base) {
-      (void)hipDeviceSynchronize();  // a frame may still be using it
-      (void)hipFree(sc->ws_base);
+      if (sc->rendered) (void)hipEventSynchronize(sc->done_event);  // a frame may still be using it
+      g_device_pool.give(sc->ws_base, sc->ws_bytes, sc->device);
       sc->ws_base = nullptr;
       sc->ws_bytes = 0;
     }
-    void* base = nullptr;
-    if (hipMalloc(&base, need) != hipSuccess)
-      return fail(RT_ERR_DEVICE, "hipMalloc of the render workspace (" + std::to_string(need >> 20) + " MiB) failed");
+    size_t cap = 0;
+    void* base = g_device_pool.take(need, sc->device, &cap);
+    if (!base) return fail(RT_ERR_DEVICE, "hipMalloc of the render workspace (" + std::to_string(need >> 20) + " MiB) failed");
     sc->ws_base = base;
-    sc->ws_bytes = need;
+    sc->ws_bytes = cap;
   }
   carve_workspace(&sc->ws, (char*)sc->ws_base, n, ratio, sc->n_lights);
   sc->ws_samples = (uint32_t)n;
@@ -954,10 +1079,15 @@ int launch_render_once(const rt_scene* scene, const rt_camera* cam, const rt_opt
       rc = (stats && !opt->timing) ? launch_stream_render<true>(scene, cam, dopt, part, n_parts, tiles_x, n_owned, packed, d_out, stream)
                                    : launch_stream_render<false>(scene, cam, dopt, part, n_parts, tiles_x, n_owned, packed, d_out, stream);
       scene->timing_on = false;
-      if (rc) return rc;
+      if (rc) {
+        (void)hipStreamSynchronize(stream);  // whatever was launched is over before the caller may destroy the scene
+        return rc;
+      }
     }
 #undef RT_LAUNCH_TILES
     HIP_TRY(hipGetLastError());
+    scene->rendered = true;
+    HIP_TRY(hipEventRecord(scene->done_event, stream));
   }
   if (stats) {
     HIP_TRY(hipEventRecord(e1, stream));
@@ -1190,24 +1320,23 @@ int rt_scene_create(const rt_scene_desc* d, rt_scene** out) {
     int cus = 0;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, sc->device) == hipSuccess && cus > 0) sc->n_cus = cus;
   }
-  void* p = nullptr;
-  if (hipMalloc(&p, RT_N_COUNTERS * sizeof(unsigned long long)) != hipSuccess) {
+  stage_bytes(sc, nullptr, RT_N_COUNTERS * sizeof(unsigned long long), (void*)&sc->d_stats);  // zero-filled
+  stage_bytes(sc, nullptr, 16, (void*)&sc->d_overflow);
+  stage_bytes(sc, nullptr, 16, (void*)&sc->d_summary);
+  rc = commit_arena(sc);
+  if (rc == RT_OK && hipEventCreateWithFlags(&sc->done_event, hipEventDisableTiming) != hipSuccess)
+    rc = fail(RT_ERR_DEVICE, "hipEventCreate failed");
+  if (rc) {
     delete sc;
-    return fail(RT_ERR_DEVICE, "hipMalloc(stats) failed");
+    return rc;
   }
-  sc->bufs.ptrs.push_back(p);
-  sc->d_stats = (unsigned long long*)p;
-  if (hipMalloc(&p, 16) != hipSuccess) {
-    delete sc;
-    return fail(RT_ERR_DEVICE, "hipMalloc(overflow) failed");
-  }
-  sc->bufs.ptrs.push_back(p);
-  sc->d_overflow = (uint32_t*)p;
   *out = sc;
   return RT_OK;
 }
 
 void rt_scene_destroy(rt_scene* scene) { delete scene; }
+
+void rt_release_cached_memory(void) { g_device_pool.clear(); }
 
 uint32_t rt_tile_count(uint32_t width, uint32_t height, uint32_t part, uint32_t n_parts) {
   if (n_parts == 0 || part >= n_parts) return 0;

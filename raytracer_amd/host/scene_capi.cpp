@@ -6,6 +6,7 @@
 #include <cstring>
 #include <fstream>
 #include <map>
+#include <mutex>
 #include <sstream>
 #include <string>
 #include <vector>
@@ -36,14 +37,36 @@ struct FlatScene {
   // scratch while flattening
   std::vector<std::vector<uint32_t>> node_children;
   std::map<std::string, uint32_t> material_index;
+
+  void reset() {  // empty, capacity kept (frames of an animation have the same sizes)
+    node_bbox.clear(); node_child_begin.clear(); child_ref.clear(); prim_shape.clear(); prim_material.clear();
+    prim_xform.clear(); prim_geom.clear(); prim_csg_left.clear(); xform_inv.clear(); tri_p1.clear(); tri_e1.clear();
+    tri_e2.clear(); tri_n1.clear(); tri_n2.clear(); tri_n3.clear(); quadric_y_min.clear(); quadric_y_max.clear();
+    quadric_closed.clear(); csg_op.clear(); csg_depth.clear(); csg_left.clear(); csg_right.clear(); material.clear();
+    pattern_c1.clear(); pattern_c2.clear(); pattern_inv.clear(); pattern_kind.clear(); light_pos.clear();
+    light_intensity.clear(); node_children.clear(); material_index.clear();
+  }
 };
 
+struct Builder;
+struct Frame {  // one rts_flatten_frame result
+  FlatScene flat;
+  ObjectPtr root;
+  Builder* owner = nullptr;
+};
 struct Builder {
   std::vector<ObjectPtr> arena;  // handles
   ObjectPtr root = make_group({});
   std::vector<Light> lights;
   FlatScene flat;
   ObjectPtr frame_root;  // animated clone kept alive while its flat tables are in use
+  // rts_flatten_frame / rts_frame_free: finished frames are kept for reuse, so that a running animation stops
+  // allocating its (large) tables: with several worker threads the page faults of fresh tables serialise them
+  std::mutex pool_mutex;
+  std::vector<Frame*> pool;
+  ~Builder() {
+    for (Frame* f : pool) delete f;
+  }
 };
 
 void push3(std::vector<double>& v, V3 a) {
@@ -467,26 +490,42 @@ int rts_flatten(void* vb, double animate_time, int build_bvh, rt_scene_desc* out
 // flattening, into tables owned by the returned frame object.  The builder is only read, so several threads may
 // prepare different frames of one builder at the same time (the frames of `animate` are independent,
 // animation_renderer.rs:61-66); rts_flatten, which keeps its tables in the builder, may not run concurrently.
-struct Frame {
-  FlatScene flat;
-  ObjectPtr root;
-};
 int rts_flatten_frame(void* vb, double animate_time, int build_bvh, void** frame_out, rt_scene_desc* out) {
-  Frame* fr = new Frame();
-  int rc = flatten_frame((const Builder*)vb, animate_time, build_bvh, fr->flat, fr->root, out);
+  Builder* b = (Builder*)vb;
+  Frame* fr = nullptr;
+  {
+    std::lock_guard<std::mutex> lock(b->pool_mutex);
+    if (!b->pool.empty()) {
+      fr = b->pool.back();
+      b->pool.pop_back();
+    }
+  }
+  if (!fr) fr = new Frame();
+  fr->owner = b;
+  fr->flat.reset();
+  int rc = flatten_frame(b, animate_time, build_bvh, fr->flat, fr->root, out);
+  // the tables are copies: release the object tree here, on the thread that built it
+  fr->root.reset();
   if (rc != 0) {
     delete fr;
     fr = nullptr;
-  } else {
-    // the tables are copies: release the object tree and the flattening scratch here, on the thread that built them
-    fr->root.reset();
-    std::vector<std::vector<uint32_t>>().swap(fr->flat.node_children);
-    fr->flat.material_index.clear();
   }
   *frame_out = fr;
   return rc;
 }
-void rts_frame_free(void* frame) { delete (Frame*)frame; }
+void rts_frame_free(void* frame) {
+  Frame* fr = (Frame*)frame;
+  if (!fr) return;
+  Builder* b = fr->owner;
+  {
+    std::lock_guard<std::mutex> lock(b->pool_mutex);
+    if (b->pool.size() < 64) {
+      b->pool.push_back(fr);
+      fr = nullptr;
+    }
+  }
+  delete fr;
+}
 
 static int flatten_frame(const Builder* b, double animate_time, int build_bvh, FlatScene& f, ObjectPtr& frame_root,
                          rt_scene_desc* out) {

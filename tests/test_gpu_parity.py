@@ -406,6 +406,31 @@ def test_leaf_size_does_not_change_pixels(monkeypatch, name):
         assert st["fallback_flags"] == 0
 
 
+def test_scenes_reuse_device_blocks_of_destroyed_scenes():
+    """rt_scene_destroy hands the scene's device blocks (table arena, render workspace) to a pool, the next scene takes
+    them (an animation makes one scene per frame): images must not depend on what the blocks held before, whichever
+    size comes after which, and rt_release_cached_memory() may be called at any time."""
+    torch = _torch()
+    L = N.core_lib()
+    setups = [Y.load_scene(scene_path("images", n), width=w, height=h, depth=5, supersampling_level=2)
+              for n, w, h in (("chapters/refractions", 96, 80), ("general/dragons", 160, 120), ("chapters/cubes", 64, 64))]
+    flats = [rs.builder.flatten() for rs in setups]
+    want = [R.render(f, rs.camera, rs.options())[0] for f, rs in zip(flats, setups)]
+    L.rt_release_cached_memory()
+    for rnd in range(3):
+        for k in (0, 1, 2, 1, 0, 2):
+            rs = setups[k]
+            sc = R.DeviceScene(flats[k])
+            out = torch.full((rs.camera.height, rs.camera.width, 3), float("nan"), dtype=torch.float64, device="cuda")
+            sc.render_device(rs.camera, rs.options(), out.data_ptr())
+            sc.render_device(rs.camera, rs.options(), out.data_ptr())
+            torch.cuda.synchronize()
+            assert np.array_equal(out.cpu().numpy(), want[k]), (rnd, k)
+            sc.close()
+        if rnd == 1:
+            L.rt_release_cached_memory()
+
+
 def test_timing_mode_reports_kernel_classes():
     torch = _torch()
     rs = Y.load_scene(scene_path("images", "general/cover"), width=256, height=256, depth=5, supersampling_level=2)

@@ -67,7 +67,10 @@ static inline hipError_t hipGetDeviceCount(int* n) { *n = 1; return hipSuccess; 
 static inline hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
 static inline hipError_t hipMalloc(void** p, size_t n) { *p = std::malloc(n); return hipSuccess; }
 static inline hipError_t hipFree(void* p) { std::free(p); return hipSuccess; }
-static inline hipError_t hipHostMalloc(void** p, size_t n) { *p = std::malloc(n); return hipSuccess; }
+enum { hipHostMallocPortable = 1, hipStreamNonBlocking = 1, hipEventDisableTiming = 2 };
+static inline hipError_t hipHostMalloc(void** p, size_t n, unsigned = 0) { *p = std::malloc(n); return hipSuccess; }
+static inline hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) { *s = nullptr; return hipSuccess; }
+static inline hipError_t hipStreamDestroy(hipStream_t) { return hipSuccess; }
 static inline hipError_t hipHostFree(void* p) { std::free(p); return hipSuccess; }
 static inline hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { std::memcpy(d, s, n); return hipSuccess; }
 static inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t) { std::memcpy(d, s, n); return hipSuccess; }
@@ -76,6 +79,7 @@ static inline hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t) {
 static inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
 static inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
 static inline hipError_t hipEventCreate(hipEvent_t* e) { *e = new hipEventRec{0.}; return hipSuccess; }
+static inline hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { *e = new hipEventRec{0.}; return hipSuccess; }
 static inline hipError_t hipEventDestroy(hipEvent_t e) { delete e; return hipSuccess; }
 static inline hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return hipSuccess; }
 static inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
