@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstring>
 #include <algorithm>
+#include <chrono>
 #include <mutex>
 #include <string>
 #include <utility>
@@ -333,12 +334,35 @@ PinnedSlots g_pinned_slots;
 
 }  // namespace
 
+// A growable byte buffer that does not zero what it grows by (unlike std::vector<char>::resize).
+struct StageBuffer {
+  char* p = nullptr;
+  size_t size = 0, cap = 0;
+  char* resize(size_t n) {
+    if (n > cap) {
+      size_t want = std::max(n, cap + cap / 2);
+      char* q = (char*)std::realloc(p, want);
+      if (!q) {
+        std::free(p);
+        p = nullptr;
+        size = cap = 0;
+        return nullptr;
+      }
+      p = q;
+      cap = want;
+    }
+    size = n;
+    return p;
+  }
+  ~StageBuffer() { std::free(p); }
+};
+
 struct rt_scene {
   DevScene dev;
   // every scene table, the statistics counters and the summary word live in ONE device block (rt_scene_create)
   void* arena = nullptr;
   size_t arena_cap = 0;
-  std::vector<char> stage;                         // while rt_scene_create runs: the arena's contents on the host
+  struct StageBuffer* stage = nullptr;             // while rt_scene_create runs: the arena's contents on the host
   std::vector<std::pair<size_t, void*>> fixups;    // (offset in the arena, address of the device pointer to set)
   int device = 0;
   mutable hipEvent_t done_event = nullptr;  // recorded after every render: what the destructor waits for
@@ -381,10 +405,16 @@ struct rt_scene {
 namespace {
 
 // Adds a table to the scene's arena image; the device pointer is set by commit_arena.
+// (the image is built in a buffer that the thread keeps: a fresh 50-MB vector costs more in page faults, ~20 ms, than
+// filling and copying it)
+thread_local StageBuffer t_stage;
 size_t stage_bytes(rt_scene* sc, const void* data, size_t bytes, void* pointer_to_set) {
-  size_t off = (sc->stage.size() + 255) & ~(size_t)255;
-  sc->stage.resize(off + std::max<size_t>(bytes, 16), 0);
-  if (bytes && data) std::memcpy(sc->stage.data() + off, data, bytes);  // no data: zeros
+  StageBuffer& st = *sc->stage;
+  size_t off = (st.size + 255) & ~(size_t)255, len = std::max<size_t>(bytes, 16);
+  char* p = st.resize(off + len);
+  if (!p) return 0;  // commit_arena reports it
+  if (bytes && data) std::memcpy(p + off, data, bytes);
+  else std::memset(p + off, 0, len);  // no data: zeros
   sc->fixups.push_back({off, pointer_to_set});
   sc->bytes += bytes;
   return off;
@@ -397,20 +427,27 @@ int upload(rt_scene* sc, const std::vector<T>& host, const T** out) {
 // One device block for everything staged, one copy (on a stream of its own: a copy on the null stream would wait for, and
 // hold up, renders of other scenes that other threads have in flight).
 int commit_arena(rt_scene* sc) {
-  size_t need = (sc->stage.size() + 255) & ~(size_t)255;
+  StageBuffer& st = *sc->stage;
+  if (!st.p) return fail(RT_ERR_DEVICE, "out of host memory while staging the scene tables");
+  size_t need = (st.size + 255) & ~(size_t)255;
   sc->arena = g_device_pool.take(need, sc->device, &sc->arena_cap);
   if (!sc->arena) return fail(RT_ERR_DEVICE, "hipMalloc of the scene tables (" + std::to_string(need >> 20) + " MiB) failed");
   hipStream_t up = nullptr;
   HIP_TRY(hipStreamCreateWithFlags(&up, hipStreamNonBlocking));
-  hipError_t e = hipMemcpyAsync(sc->arena, sc->stage.data(), sc->stage.size(), hipMemcpyHostToDevice, up);
+  auto t0 = std::chrono::steady_clock::now();
+  hipError_t e = hipMemcpyWithStream(sc->arena, st.p, st.size, hipMemcpyHostToDevice, up);
   if (e == hipSuccess) e = hipStreamSynchronize(up);
+  if (std::getenv("RT_DEBUG_TIMING"))
+    fprintf(stderr, "[rtcore] arena copy %zu bytes: %.2f ms\n", st.size,
+            std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
   (void)hipStreamDestroy(up);
   if (e != hipSuccess) return fail(RT_ERR_DEVICE, std::string("upload of the scene tables failed: ") + hipGetErrorString(e));
   for (auto& f : sc->fixups) {
     void* p = (char*)sc->arena + f.first;
     std::memcpy(f.second, &p, sizeof(p));
   }
-  std::vector<char>().swap(sc->stage);
+  st.size = 0;  // capacity kept
+  sc->stage = nullptr;
   sc->fixups.clear();
   return RT_OK;
 }
@@ -1174,6 +1211,7 @@ int rt_device_count(void) {
 }
 
 int rt_scene_create(const rt_scene_desc* d, rt_scene** out) {
+  auto t_create = std::chrono::steady_clock::now();
   if (!out) return fail(RT_ERR_INVALID_ARGUMENT, "out is NULL");
   *out = nullptr;
   int rc = validate(d);
@@ -1236,7 +1274,11 @@ int rt_scene_create(const rt_scene_desc* d, rt_scene** out) {
     quadric[i * 2 + 1] = d->quadric_y_max[i];
   }
 
+  if (std::getenv("RT_DEBUG_TIMING"))
+    fprintf(stderr, "[rtcore] layout: %.2f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_create).count());
   rt_scene* sc = new rt_scene();
+  t_stage.size = 0;
+  sc->stage = &t_stage;
   (void)hipGetDevice(&sc->device);
   sc->stack_need = need;
 #define UP(vec, field)                                 \
@@ -1323,6 +1365,8 @@ int rt_scene_create(const rt_scene_desc* d, rt_scene** out) {
   stage_bytes(sc, nullptr, RT_N_COUNTERS * sizeof(unsigned long long), (void*)&sc->d_stats);  // zero-filled
   stage_bytes(sc, nullptr, 16, (void*)&sc->d_overflow);
   stage_bytes(sc, nullptr, 16, (void*)&sc->d_summary);
+  if (std::getenv("RT_DEBUG_TIMING"))
+    fprintf(stderr, "[rtcore] staged: %.2f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_create).count());
   rc = commit_arena(sc);
   if (rc == RT_OK && hipEventCreateWithFlags(&sc->done_event, hipEventDisableTiming) != hipSuccess)
     rc = fail(RT_ERR_DEVICE, "hipEventCreate failed");
