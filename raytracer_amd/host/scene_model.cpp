@@ -676,18 +676,44 @@ void build_items(Object& g, std::vector<BuildItem>& items, size_t lo, size_t hi,
       side_add(cls[axis][m], &it.bb.min.x, &it.bb.max.x, it.count);
     }
   }
+  // Both sides of every candidate.  Ordered candidate positions (the normal case) leave only the classes "below none",
+  // "below the last", "below the last two", ...: candidate i's left side is then a prefix of those and its right side
+  // the matching suffix (5 + 5 unions per axis); any other class (NaN positions) takes the general path.
+  SideSum left[CANDIDATE_POS_NUMBER][3], right[CANDIDATE_POS_NUMBER][3];
+  for (int axis = 0; axis < 3; axis++) {
+    constexpr uint32_t ORDERED = (1u << 0) | (1u << 16) | (1u << 24) | (1u << 28) | (1u << 30) | (1u << 31);
+    if ((used[axis] & ~ORDERED) == 0) {
+      // class k (k = 0..5) = centres below the candidates k..4 only: mask (0b11111 << k) & 31
+      SideSum run;
+      side_reset(run);
+      for (int i = 0; i < CANDIDATE_POS_NUMBER; i++) {  // left of candidate i: classes 0..i
+        unsigned m = (0x1Fu << i) & 0x1Fu;
+        if ((used[axis] >> m) & 1u) side_add(run, cls[axis][m].mn, cls[axis][m].mx, cls[axis][m].count);
+        left[i][axis] = run;
+      }
+      side_reset(run);
+      for (int i = CANDIDATE_POS_NUMBER - 1; i >= 0; i--) {  // right of candidate i: classes i+1..5
+        unsigned m = (0x1Fu << (i + 1)) & 0x1Fu;
+        if ((used[axis] >> m) & 1u) side_add(run, cls[axis][m].mn, cls[axis][m].mx, cls[axis][m].count);
+        right[i][axis] = run;
+      }
+    } else {
+      for (int i = 0; i < CANDIDATE_POS_NUMBER; i++) {
+        side_reset(left[i][axis]);
+        side_reset(right[i][axis]);
+        for (uint32_t rest = used[axis]; rest; rest &= rest - 1) {
+          unsigned m = (unsigned)__builtin_ctz(rest);
+          const SideSum& c = cls[axis][m];
+          side_add(((m >> i) & 1u) ? left[i][axis] : right[i][axis], c.mn, c.mx, c.count);
+        }
+      }
+    }
+  }
   int best_axis = 0;
   double best_pos = 0.0, best_cost = INFINITY;
   for (int i = 0; i < CANDIDATE_POS_NUMBER; i++)
     for (int axis = 0; axis < 3; axis++) {  // group.rs:96-105, :109-129
-      SideSum l, r;
-      side_reset(l);
-      side_reset(r);
-      for (uint32_t rest = used[axis]; rest; rest &= rest - 1) {
-        unsigned m = (unsigned)__builtin_ctz(rest);
-        const SideSum& c = cls[axis][m];
-        side_add(((m >> i) & 1u) ? l : r, c.mn, c.mx, c.count);
-      }
+      const SideSum &l = left[i][axis], &r = right[i][axis];
       double cost = (l.count == 0 || r.count == 0) ? INFINITY
                                                    : side_half_area(l) * (double)l.count + side_half_area(r) * (double)r.count;
       if (cost < best_cost) {
