@@ -23,6 +23,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+FP64_PEAK_TFLOPS = 78.6  # MI355X_MICROARCH.md: vector FP64 peak (no matrix cores on this path)
 
 WORKLOADS = {
     # name: (scene file, width, height, supersampling level, depth)
@@ -215,6 +216,14 @@ def main():
             kname, k_ms, k_launches, k_bytes = "stream::trace_shadow_kernel<false>", tm["ms_trace_shadow"], tm["launches_trace_shadow"], shadow_bytes
         else:
             kname, k_ms, k_launches, k_bytes = "stream::trace_closest_kernel<true, false>", tm["ms_trace_closest"], tm["launches_trace_closest"], closest_bytes
+        # the same kernel against the FP64 vector peak (SURVEY.md §8d flop constants: a box test = 12 mul/sub + 10 min/max/
+        # compare, a triangle test = 45 when it runs to completion (early exits are not separated: an upper bound), an
+        # analytic-primitive test = 18 for the ray transform + ~22 for the shape)
+        if kname.startswith("stream::trace_shadow"):
+            k_flops = 22 * r0["shadow_node_visits"] + 45 * r0["shadow_tri_tests"] + 40 * r0["shadow_prim_tests"]
+        else:
+            k_flops = (22 * (r0["node_visits"] - r0["shadow_node_visits"]) + 45 * (r0["tri_tests"] - r0["shadow_tri_tests"]) +
+                       40 * (r0["prim_tests"] - r0["shadow_prim_tests"]))
         k_launches = max(1.0, k_launches)
         achieved = k_bytes / max(1e-9, k_ms * 1e-3) / 1e9  # (bytes per launch) / (duration per launch)
         frame_bytes = float(algorithmic_bytes(r0, n_pix_rank))
@@ -238,6 +247,10 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": kname, "kernel_ms": k_ms / k_launches, "launches_per_step": k_launches,
+                         "fp64_vector": {"achieved": k_flops / max(1e-9, k_ms * 1e-3) / 1e12, "peak": FP64_PEAK_TFLOPS,
+                                         "unit": "TFLOP/s", "frac": k_flops / max(1e-9, k_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,
+                                         "note": "algorithmic flops of the same launches (22 per box test, 45 per triangle "
+                                                 "test, 40 per analytic-primitive test) / the same durations"},
                          "algorithmic_bytes_per_launch": k_bytes / k_launches,
                          "whole_frame": {"ms_gpu": tm["ms_kernel"], "algorithmic_bytes": frame_bytes,
                                          "achieved": frame_bytes / max(1e-9, tm["ms_kernel"] * 1e-3) / 1e9,
