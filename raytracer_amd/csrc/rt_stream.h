@@ -292,7 +292,7 @@ __device__ __forceinline__ void flag_sample(const Ws& w, uint32_t root) {
 #define RT_REFILL_BELOW 1
 #endif
 #ifndef RT_REFILL_BELOW
-#define RT_REFILL_BELOW 16
+#define RT_REFILL_BELOW 24
 #endif
 
 #ifndef RT_CLOSEST_WAVES
