@@ -784,6 +784,14 @@ __global__ __launch_bounds__(64, 2) void fallback_kernel(DevScene s, rt_camera c
                                                          unsigned long long* stats, uint32_t* summary,
                                                          uint32_t* overflow_flag) {
   __shared__ uint2 lds_stack[RT_LDS_STACK * 64];
+  // summary[1]: node records this batch used per sample, in sixteenths, rounded up (largest batch of the frame): what the
+  // host sizes the following frames' batches by
+  if (blockIdx.x == 0 && threadIdx.x == 0 && b.n_samples) {
+    atomicMax(&summary[1], (uint32_t)(((unsigned long long)w.ctrl->n_nodes * 16ull + b.n_samples - 1u) / b.n_samples));
+    uint32_t most_rays = 0;  // summary[2]: the same for the longest ray queue of a deeper level
+    for (uint32_t l = 1; l <= RT_LEVELS; l++) most_rays = max(most_rays, w.ctrl->n_rays[l]);
+    atomicMax(&summary[2], (uint32_t)(((unsigned long long)most_rays * 16ull + b.n_samples - 1u) / b.n_samples));
+  }
   if (w.ctrl->n_flagged == 0) return;
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     atomicAdd(summary, w.ctrl->n_flagged);

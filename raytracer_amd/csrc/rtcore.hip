@@ -381,7 +381,8 @@ struct rt_scene {
   // node records per sample the batches are laid out for.  A sample whose ray tree needs more is re-rendered by the
   // fallback kernel (same pixels, slower); the count of such events comes back with every frame and doubles this.
   mutable uint32_t nodes_per_sample = 3;
-  mutable uint32_t* d_summary = nullptr;  // [1] fallback flags of the frame in flight
+  mutable uint32_t ratio_floor = 1;  // smallest ratio worth trying again (one more than the last that overflowed)
+  mutable uint32_t* d_summary = nullptr;  // [0] fallback flags of the frame in flight, [1] / [2] node records / rays of a level used per sample, x 16
   mutable uint32_t* h_summary = nullptr;  // pinned copy, valid once summary_event has completed
   mutable hipEvent_t summary_event = nullptr;
   mutable bool summary_pending = false;
@@ -899,11 +900,24 @@ size_t carve_workspace(stream::Ws* w, char* base, uint64_t n, uint32_t ratio, ui
 void absorb_summary(const rt_scene* sc) {
   if (!sc->summary_pending || hipEventQuery(sc->summary_event) != hipSuccess) return;
   sc->summary_pending = false;
-  if (sc->h_summary[0] > 0 && sc->nodes_per_sample < RT_STREAM_RATIO_MAX) sc->nodes_per_sample *= 2;
+  if (sc->h_summary[0] > 0) {
+    sc->ratio_floor = std::min<uint32_t>(sc->nodes_per_sample + 1u, RT_STREAM_RATIO_MAX);  // this ratio was too small once
+    if (sc->nodes_per_sample < RT_STREAM_RATIO_MAX) sc->nodes_per_sample *= 2;
+  } else if (sc->h_summary[1] > 0) {
+    // nothing overflowed: lay the next frames out for what this one used plus a quarter (never more than now, never a
+    // ratio that has overflowed before).  Fewer records per sample = more samples per batch, and every batch has fixed
+    // costs (a 4K frame at 16 spp uses 0.35 node records per sample: one batch instead of two, 46.8 -> 43.1 ms).
+    // The ray queues hold max(1, ratio / 2) rays per sample (batch_caps).
+    uint32_t want = std::max<uint32_t>(1u, (sc->h_summary[1] * 5u / 4u + 15u) / 16u);
+    uint32_t rays = (sc->h_summary[2] * 5u / 4u + 15u) / 16u;
+    if (rays > 1u) want = std::max(want, 2u * rays);
+    want = std::max(want, sc->ratio_floor);
+    if (want < sc->nodes_per_sample) sc->nodes_per_sample = want;
+  }
 }
 
 // Lays the scene's workspace out for batches of up to min(want, limit) samples at the scene's current nodes-per-sample
-// ratio, (re)allocating when it is too small.  limit: RT_STREAM_BATCH_SAMPLES (default 64 Mi samples: every launch of a
+// ratio, (re)allocating when it is too small.  limit: RT_STREAM_BATCH_SAMPLES (default 256 Mi samples: every launch of a
 // persistent kernel has a fixed cost, 2 batches per 4K frame measured 5 % faster than 4), and the workspace
 // never takes more than a third of the device's free memory.
 int ensure_workspace(const rt_scene* sc, uint64_t want_samples, uint32_t* batch_samples) {
@@ -911,17 +925,17 @@ int ensure_workspace(const rt_scene* sc, uint64_t want_samples, uint32_t* batch_
     sc->h_summary = g_pinned_slots.take();
     if (!sc->h_summary || hipEventCreate(&sc->summary_event) != hipSuccess)
       return fail(RT_ERR_DEVICE, "allocation of the frame summary failed");
-    sc->h_summary[0] = 0;
+    sc->h_summary[0] = sc->h_summary[1] = sc->h_summary[2] = 0;
   }
   absorb_summary(sc);
   const uint32_t ratio = sc->nodes_per_sample;
-  uint64_t limit = 64ull << 20;
+  uint64_t limit = 256ull << 20;
   if (const char* e = std::getenv("RT_STREAM_BATCH_SAMPLES")) {
     unsigned long long v = std::strtoull(e, nullptr, 10);
     if (v >= 64) limit = v;
   }
   // node ids carry two flag bits, and (node, light) items are counted in 32 bits
-  limit = std::min<uint64_t>(limit, ((1ull << 30) / ratio) / std::max<uint32_t>(sc->n_lights, 1u));
+  limit = std::min<uint64_t>(limit, std::min<uint64_t>((1ull << 30) / ratio, ((1ull << 32) - 1) / ((uint64_t)ratio * std::max<uint32_t>(sc->n_lights, 1u))));
   uint64_t n = std::max<uint64_t>(align_up(std::min<uint64_t>(want_samples, limit), 64), 64);
   size_t need = carve_workspace(nullptr, nullptr, n, ratio, sc->n_lights);
   if (need > sc->ws_bytes) {
@@ -961,8 +975,8 @@ int ensure_workspace(const rt_scene* sc, uint64_t want_samples, uint32_t* batch_
 // After the last batch of a frame: its fallback count travels to the host without stalling anything.
 int post_summary(const rt_scene* sc, hipStream_t st) {
   if (sc->summary_pending) return RT_OK;  // the previous one has not been read yet; this frame's count is dropped
-  HIP_TRY(hipMemcpyAsync(sc->h_summary, sc->d_summary, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-  HIP_TRY(hipMemsetAsync(sc->d_summary, 0, sizeof(uint32_t), st));
+  HIP_TRY(hipMemcpyAsync(sc->h_summary, sc->d_summary, 3 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipMemsetAsync(sc->d_summary, 0, 3 * sizeof(uint32_t), st));
   HIP_TRY(hipEventRecord(sc->summary_event, st));
   sc->summary_pending = true;
   return RT_OK;

@@ -44,6 +44,7 @@ template <class T> static inline T __shfl(T v, int, int) { return v; }
 #define __HIP_MEMORY_SCOPE_AGENT 0
 template <class T> static inline T __hip_atomic_load(T* p, int, int) { return *p; }
 template <class T> static inline T atomicAdd(T* p, T v) { T o = *p; *p += v; return o; }
+static inline uint32_t atomicMax(uint32_t* p, uint32_t v) { uint32_t o = *p; if (v > o) *p = v; return o; }
 static inline uint32_t atomicOr(uint32_t* p, uint32_t v) { uint32_t o = *p; *p |= v; return o; }
 
 typedef int hipError_t;
