@@ -76,25 +76,12 @@ __device__ __forceinline__ d3 mat_transposed_vector(const double* __restrict__ m
 #define RT_FREF_NONE 0xFFFFFFFFu  // kind EMPTY: nothing left to visit
 #define RT_MAKE_FREF(kind, count, index) (((uint32_t)(kind) << RT_FREF_KIND_SHIFT) | ((uint32_t)(count) << RT_FREF_COUNT_SHIFT) | (uint32_t)(index))
 
-#ifndef RT_NODE_WIDTH
-#define RT_NODE_WIDTH 4  // 2 or 4 (2: the reference's binary tree as it is, 64-B nodes)
-#endif
-#ifndef RT_NODE_F64
-#define RT_NODE_F64 0  // 1: boxes kept as f64 (256-B nodes for width 4): no f32 -> f64 conversions in the node step, twice the bytes
-#endif
-#if RT_NODE_F64
-struct __attribute__((aligned(64 * RT_NODE_WIDTH))) DevNode {
-  double bb[RT_NODE_WIDTH][6];  // child boxes exactly as the reference holds them (bounding_box.rs:25-28)
-  uint32_t ref[RT_NODE_WIDTH];
-  uint32_t pad[3 * RT_NODE_WIDTH];
-};
-#else
-struct __attribute__((aligned(32 * RT_NODE_WIDTH))) DevNode {
+#define RT_NODE_WIDTH 4
+struct __attribute__((aligned(128))) DevNode {
   float bb[RT_NODE_WIDTH][6];   // child boxes: min x,y,z (rounded down), max x,y,z (rounded up) (bounding_box.rs:25-28)
   uint32_t ref[RT_NODE_WIDTH];  // RT_MAKE_FREF; unused slots hold RT_FREF_NONE and come last
   uint32_t pad[RT_NODE_WIDTH];
 };
-#endif
 
 // Triangles are stored in leaf order, RT_TRI_STRIDE doubles each (80 B, 16-B aligned): p1, e1, e2, then the
 // primitive index in the low 32 bits of the tenth slot.

@@ -50,9 +50,34 @@ struct Trav {
   uint32_t odd;   // 1: a component of dinv is not finite (an axis-parallel ray): 0 * inf = NaN can occur in the slab test,
                   // whose outcome then depends on the reference's operand order (see box_times)
   uint32_t cur;   // reference being visited, RT_FREF_NONE when nothing is left to visit
-  uint32_t pending;  // RT_SPECULATE: a leaf reached but not yet intersected (the lane went on down the tree meanwhile)
   int sp;
+  // The ray in f32, for the conservative slab test of the node step (box_keys_f32): t_f = fma(b, fdi, fno) with
+  // fdi = (float)dinv and fno = (float)-(o * dinv), per axis; ferr bounds what the roundings of fdi and fno can move t_f by
+  // (absolute part; the relative part is RT_SLAB_REL); limf = an f32 no less than near_limit(limit).
+  float fdx, fdy, fdz, fnx, fny, fnz, ferr, limf;
 };
+
+// Where the reference can differ from "smallest t, ties to the smallest rank": it skips a popped group when
+// t_enter >= closest t so far (group.rs:182).  A primitive lying ON a face of its group's box has t within rounding of
+// that t_enter, so when a SECOND surface coincides with it (dragons.yml: the glass cubes stand on the pedestal caps) the
+// reference may never test the nearer of the two.  Such a ray is recognised by a runner-up intersection within
+// RT_TIE_WINDOW of the hit and is re-traced in the reference's own order (reforder::traverse); for every other ray the
+// candidate sets are identical and so is the hit.  Boxes are therefore kept while they are entered within the window.
+#define RT_TIE_WINDOW 1.0e-10
+__device__ __forceinline__ double near_limit(double limit) { return limit + RT_TIE_WINDOW * fmax(1., limit); }
+
+// An f32 no less than x (x > 0 or +inf): the nearest f32 moved up by at least its last bit.
+__device__ __forceinline__ float f32_above(double x) {
+  float f = (float)x;
+  return __builtin_fmaf(fabsf(f), 1.1920929e-07f, f);
+}
+
+// Relative and absolute slack of the f32 slab test (see box_keys_f32).  With u = 2^-24: t_f = fma(b, fdi, fno) differs
+// from the exact (b - o) * dinv by at most 2u |t| + 2u (1 + u) |o dinv| (fdi and fno are each one rounding away from
+// dinv and -o dinv, the fma adds one more); both parts are taken three times over, which also covers the roundings of
+// the slack arithmetic itself.
+#define RT_SLAB_REL 3.5762787e-07f  // 6u
+#define RT_SLAB_ABS_MIN 1.0e-30f    // floor of the absolute part (o = 0 makes it 0 otherwise)
 
 __device__ __forceinline__ void trav_start(Trav& T, d3 o, d3 d, uint32_t mode, double limit) {
   T.o = o;
@@ -60,9 +85,23 @@ __device__ __forceinline__ void trav_start(Trav& T, d3 o, d3 d, uint32_t mode, d
   T.dinv = mk3(1. / d.x, 1. / d.y, 1. / d.z);  // Ray::new (ray.rs:27-34)
   T.limit = limit;
   T.mode = mode;
-  T.odd = (fabs(T.dinv.x) < INFINITY && fabs(T.dinv.y) < INFINITY && fabs(T.dinv.z) < INFINITY) ? 0u : 1u;
+  {
+    double px = o.x * T.dinv.x, py = o.y * T.dinv.y, pz = o.z * T.dinv.z;
+    T.fdx = (float)T.dinv.x;
+    T.fdy = (float)T.dinv.y;
+    T.fdz = (float)T.dinv.z;
+    T.fnx = (float)-px;
+    T.fny = (float)-py;
+    T.fnz = (float)-pz;
+    float m = fmaxf(fmaxf(fabsf(T.fnx), fabsf(T.fny)), fabsf(T.fnz));
+    T.ferr = fmaxf(m * RT_SLAB_REL, RT_SLAB_ABS_MIN);
+    T.limf = f32_above(near_limit(limit));
+    // the f32 test needs all six finite (an axis-parallel ray has dinv = inf, and 0 * inf = NaN there is decided by the
+    // reference's operand order: such rays take the exact f64 test)
+    bool fin = fabsf(T.fdx) < INFINITY && fabsf(T.fdy) < INFINITY && fabsf(T.fdz) < INFINITY && m < INFINITY && T.ferr < INFINITY;
+    T.odd = fin ? 0u : 1u;
+  }
   T.cur = RT_MAKE_FREF(RT_FREF_INNER, 0, 0);
-  T.pending = RT_FREF_NONE;
   T.sp = 0;
   if (mode == M_CLOSEST) {
     T.p = RT_NONE;
@@ -97,6 +136,7 @@ __device__ __forceinline__ void add_roots(const DevScene& s, Trav& T, uint32_t p
       if (T.p != prim) T.t2 = fmin(T.t2, take ? T.limit : t);  // the dethroned hit, or this rejected one
       if (take) {
         T.limit = t;
+        T.limf = f32_above(near_limit(t));
         T.p = prim;
         T.a = u;
         T.b = v;
@@ -187,9 +227,6 @@ __device__ __forceinline__ bool box_times(const double* __restrict__ bb, d3 o, d
   return !(tmin > tmax);
 }
 
-// The same for a ray whose dinv is finite in every component: no operand can be NaN then, and "order by a < b"
-// (bounding_box.rs:141-153) is min/max (equal values, whichever way round, compare the same afterwards), which costs 6
-// instructions per box instead of 15.
 #ifdef RT_HOST_EMU
 __device__ __forceinline__ double min_f64(double a, double b) { return fmin(a, b); }
 __device__ __forceinline__ double max_f64(double a, double b) { return fmax(a, b); }
@@ -206,23 +243,6 @@ __device__ __forceinline__ double max_f64(double a, double b) {
   return r;
 }
 #endif
-__device__ __forceinline__ bool box_times_finite(const double* __restrict__ bb, d3 o, d3 dinv, double& tmin, double& tmax) {
-  double ax = (bb[0] - o.x) * dinv.x, bx = (bb[3] - o.x) * dinv.x;
-  double ay = (bb[1] - o.y) * dinv.y, by = (bb[4] - o.y) * dinv.y;
-  double az = (bb[2] - o.z) * dinv.z, bz = (bb[5] - o.z) * dinv.z;
-  tmin = max_f64(max_f64(min_f64(ax, bx), min_f64(ay, by)), min_f64(az, bz));
-  tmax = min_f64(min_f64(max_f64(ax, bx), max_f64(ay, by)), max_f64(az, bz));
-  return !(tmin > tmax);
-}
-
-// Where the reference can differ from "smallest t, ties to the smallest rank": it skips a popped group when
-// t_enter >= closest t so far (group.rs:182).  A primitive lying ON a face of its group's box has t within rounding of
-// that t_enter, so when a SECOND surface coincides with it (dragons.yml: the glass cubes stand on the pedestal caps) the
-// reference may never test the nearer of the two.  Such a ray is recognised by a runner-up intersection within
-// RT_TIE_WINDOW of the hit and is re-traced in the reference's own order (reforder::traverse); for every other ray the
-// candidate sets are identical and so is the hit.  Boxes are therefore kept while they are entered within the window.
-#define RT_TIE_WINDOW 1.0e-10
-__device__ __forceinline__ double near_limit(double limit) { return limit + RT_TIE_WINDOW * fmax(1., limit); }
 
 // Keeps the compiler from sinking these loads below a later branch: they are all issued, and waited for, here.
 __device__ __forceinline__ void pin_loaded(double2& a, double2& b, double2& c, double2& d, double2& e) {
@@ -237,24 +257,69 @@ __device__ __forceinline__ float key_below(double t) {
   return fminf(fmaf(-fabsf(k), 1.1920929e-07f, k), 3.4028234e38f);
 }
 
-// Coordinate k of child c's box in a node fetched as 32-bit words.
-__device__ __forceinline__ double node_box_value(const uint32_t* raw, int c, int k) {
-#if RT_NODE_F64
-  return __longlong_as_double((long long)(((unsigned long long)raw[2 * (6 * c + k) + 1] << 32) | raw[2 * (6 * c + k)]));
-#else
-  return (double)__uint_as_float(raw[6 * c + k]);
-#endif
+// ---------------------------------------------------------------------------------------------
+// The node step's box test.
+//
+// A box only ever CULLS: which intersection wins is decided by the exact f64 primitive tests, the visit ranks and the tie
+// re-trace, so the test may keep any box the reference's f64 slab test (bounding_box.rs:192-225) keeps and more.  The
+// node's boxes are already the reference's boxes rounded outward to f32; for a ray without an infinite dinv component
+// the slab test itself is done in f32 on INTERVALS: per axis t_f = fma(b, fdi, fno) for both planes, entry = max over the
+// axes of the smaller, exit = min of the larger (no rounding in min / max), and then
+//     lo = entry - RT_SLAB_REL |entry| - ferr   <=  the exact entry time   (Trav::ferr, RT_SLAB_REL: error bound of t_f)
+//     hi = exit  + RT_SLAB_REL |exit|  + ferr   >=  the exact exit time
+// (x -> x -+ rel |x| -+ err is monotone, so it commutes with the min / max over axes and planes).  The box is visited
+// unless max(lo, floor) > min(hi, limf): floor = 0 for closest-hit and shadow rays, which also culls the boxes entirely
+// behind the origin (hi < 0) — their intersections have t < 0 —, and -inf for the container walk, which wants exactly
+// those.  Every comparison is written so that a NaN (inf - inf on absurd coordinates) keeps the box.
+// What the f32 test costs: 14 VALU instructions per box instead of 30 (no f32 -> f64 conversions, fma instead of sub +
+// mul, v_min3 / v_max3), and its key is already the f32 lower bound the stack keeps.
+// key: >= RT_KEY_MIN (so that (key, ref) read as a u64 / f64 is a normal, ordered number), +inf = do not visit.
+// ---------------------------------------------------------------------------------------------
+#define RT_KEY_MIN 1.17549435e-38f
+#define RT_KEY_NONE 0x7F800000u  // bits of +inf
+
+__device__ __forceinline__ uint32_t box_key_f32(const Trav& T, const uint32_t* __restrict__ raw, int c, float floorv, uint32_t ref) {
+  const float b0 = __uint_as_float(raw[6 * c + 0]), b1 = __uint_as_float(raw[6 * c + 1]), b2 = __uint_as_float(raw[6 * c + 2]);
+  const float b3 = __uint_as_float(raw[6 * c + 3]), b4 = __uint_as_float(raw[6 * c + 4]), b5 = __uint_as_float(raw[6 * c + 5]);
+  const float x0 = __builtin_fmaf(b0, T.fdx, T.fnx), x1 = __builtin_fmaf(b3, T.fdx, T.fnx);
+  const float y0 = __builtin_fmaf(b1, T.fdy, T.fny), y1 = __builtin_fmaf(b4, T.fdy, T.fny);
+  const float z0 = __builtin_fmaf(b2, T.fdz, T.fnz), z1 = __builtin_fmaf(b5, T.fdz, T.fnz);
+  const float entry = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fminf(z0, z1));
+  const float exit_ = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fmaxf(z0, z1));
+  const float lo = __builtin_fmaf(-fabsf(entry), RT_SLAB_REL, entry) - T.ferr;
+  const float hi = __builtin_fmaf(fabsf(exit_), RT_SLAB_REL, exit_) + T.ferr;
+  const bool visit = !(fmaxf(lo, floorv) > fminf(hi, T.limf)) & (ref != RT_FREF_NONE);
+  return visit ? __float_as_uint(fmaxf(lo, RT_KEY_MIN)) : RT_KEY_NONE;
 }
 
-__device__ __forceinline__ void stack_push(Trav& T, uint2* lds, uint2* ovf, uint32_t ref, float t_rd, Counters& cnt) {
+// The exact test (the reference's own arithmetic on the node's boxes) for wavefronts holding an axis-parallel ray.
+template <int MS>
+__device__ __forceinline__ uint32_t box_key_f64(const Trav& T, const uint32_t* __restrict__ raw, int c, bool all_t, uint32_t ref) {
+  double bb[6], tmin, tmax;
+  for (int k = 0; k < 6; k++) bb[k] = (double)__uint_as_float(raw[6 * c + k]);
+  bool hit = box_times(bb, T.o, T.dinv, tmin, tmax);
+  // a box can hold an accepted intersection only if it is entered no later than the limit (plus the window in which a
+  // runner-up must still be seen, see near_limit) and, for t >= 0 intersections, is not entirely behind the origin
+  bool h = hit & !(tmin > near_limit(T.limit)) & (all_t | !(tmax < 0.)) & (ref != RT_FREF_NONE);
+  return h ? __float_as_uint(fmaxf(key_below(tmin), RT_KEY_MIN)) : RT_KEY_NONE;
+}
+
+// A stack entry: reference in the low word, key (f32 bits, a lower bound of the entry time) in the high word.
+__device__ __forceinline__ double pack_entry(uint32_t ref, uint32_t key_bits) {
+  return __longlong_as_double((long long)(((unsigned long long)key_bits << 32) | ref));
+}
+__device__ __forceinline__ uint32_t entry_ref(double e) { return (uint32_t)(unsigned long long)__double_as_longlong(e); }
+__device__ __forceinline__ uint32_t entry_key(double e) { return (uint32_t)((unsigned long long)__double_as_longlong(e) >> 32); }
+
+__device__ __forceinline__ void stack_push(Trav& T, uint2* lds, uint2* ovf, double entry) {
   // (the two branches store differently shaped values on purpose: identical stores get merged into one FLAT store through
   // a selected pointer, which takes the slow path through both the LDS and the memory pipeline — on every push)
   if (T.sp < RT_LDS_STACK) {
-    *reinterpret_cast<unsigned long long*>(&lds[T.sp * 64]) = (unsigned long long)ref | ((unsigned long long)__float_as_uint(t_rd) << 32);
+    *reinterpret_cast<double*>(&lds[T.sp * 64]) = entry;
   } else {
     int i = min(T.sp - RT_LDS_STACK, RT_OVF_STACK - 1);  // cannot run over: rt_scene_create rejects a tree that needs more
-    ovf[i].x = ref;                                       // than RT_FAST_STACK_MAX entries (the clamp only keeps a bug inside
-    ovf[i].y = __float_as_uint(t_rd);                     // the array)
+    ovf[i].x = entry_ref(entry);                         // than RT_FAST_STACK_MAX entries (the clamp only keeps a bug inside
+    ovf[i].y = entry_key(entry);                         // the array)
   }
   T.sp++;
 }
@@ -268,7 +333,7 @@ __device__ __forceinline__ uint32_t stack_pop(Trav& T, const uint2* lds, const u
       e.x = v[T.sp - RT_LDS_STACK].x;
       e.y = v[T.sp - RT_LDS_STACK].y;
     }
-    if (!((double)__uint_as_float(e.y) > near_limit(T.limit))) return e.x;  // still able to hold an accepted intersection
+    if (!(__uint_as_float(e.y) > T.limf)) return e.x;  // still able to hold an accepted intersection
   }
   return RT_FREF_NONE;
 }
@@ -282,16 +347,20 @@ __device__ __forceinline__ void count_step(Counters& cnt) {  // statistics build
   if ((uint32_t)(__ffsll((long long)active) - 1) == (threadIdx.x & 63u)) cnt.wave_steps++;
 }
 
-// RT_SPECULATE = 1: a lane that reaches a leaf while other lanes of its wavefront are still descending does not wait for
-// them: it keeps the leaf as `pending`, pops its stack and goes on descending; the pending leaf is intersected when the
-// wavefront next does leaves.  More lanes are busy in both phases; the price is box tests a nearer hit in the pending leaf
-// would have culled (never a different result: culling by the limit is only ever an optimisation).
-#ifndef RT_SPECULATE
-#define RT_SPECULATE 0
+__device__ __forceinline__ bool trav_busy(const Trav& T) { return T.cur != RT_FREF_NONE; }
+
+// Shadow rays do not need the nearest child first (every intersection before the light counts, in any order);
+// RT_SHADOW_SORT = 0 visits a node's children in slot order instead.
+#ifndef RT_SHADOW_SORT
+#define RT_SHADOW_SORT 0  // measured: 18.90 -> 18.40 ms for the 4K frame's shadow rays without the sort
 #endif
-__device__ __forceinline__ bool trav_busy(const Trav& T) {
-  return T.cur != RT_FREF_NONE || (RT_SPECULATE && T.pending != RT_FREF_NONE);
-}
+
+// The node loop is left early when fewer than RT_NODE_BREAK lanes are still descending while other lanes of the wavefront
+// already hold a leaf: those lanes are served first and the descent resumes afterwards (0: every lane descends to a leaf
+// before any leaf is done).  Measured on the 4K frame: 8-16 equally good (38.95 -> 37.0 ms), 20 less so, 28 none.
+#ifndef RT_NODE_BREAK
+#define RT_NODE_BREAK 16
+#endif
 
 // Runs the lane's traversal to completion (lanes that are not trav_busy have nothing to do).
 // min_active > 0 (the streamed kernels, rt_stream.h): the loop is left, with the unfinished lanes' state intact, as soon as
@@ -302,17 +371,22 @@ __device__ __forceinline__ void trav_run(const DevScene& s, Trav& T, uint2* lds,
     if (min_active && (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(true)) < min_active) break;
     unsigned long long tc0 = (STATS && min_active) ? (unsigned long long)clock64() : 0ull;
     // ---- inner nodes: descend until this lane holds a leaf (or runs out of work) ----
+#if RT_NODE_BREAK
+    const uint32_t busy0 = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(true));
+#endif
     for (;;) {
-      if (RT_SPECULATE && T.pending == RT_FREF_NONE && T.cur != RT_FREF_NONE && (T.cur >> RT_FREF_KIND_SHIFT) != RT_FREF_INNER) {
-        T.pending = T.cur;
-        T.cur = stack_pop(T, lds, ovf);
-      }
       if ((T.cur >> RT_FREF_KIND_SHIFT) != RT_FREF_INNER) break;
+#if RT_NODE_BREAK
+      if (min_active) {  // few lanes still descending while others hold leaves: do the leaves first
+        uint32_t act = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(true));
+        if (act < (uint32_t)RT_NODE_BREAK && act < busy0) break;
+      }
+#endif
       if (STATS) count_step(cnt);
       // The whole node is fetched first (16-B loads, all in flight together), then tested: written out by hand because
       // the compiler otherwise fetches and waits box by box.
       const uint4* np = reinterpret_cast<const uint4*>(s.nodes + (T.cur & RT_FREF_INDEX_MASK));
-      constexpr int NQ = RT_NODE_F64 ? (RT_NODE_WIDTH * 13 + 3) / 4 : (RT_NODE_WIDTH * 7 + 3) / 4;
+      constexpr int NQ = 7;
       uint4 q[NQ];
       for (int k = 0; k < NQ; k++) q[k] = np[k];
       uint32_t raw[NQ * 4];
@@ -322,73 +396,86 @@ __device__ __forceinline__ void trav_run(const DevScene& s, Trav& T, uint2* lds,
         raw[4 * k + 2] = q[k].z;
         raw[4 * k + 3] = q[k].w;
       }
-      // a box can hold an accepted intersection only if it is entered no later than the limit (plus the window in
-      // which a runner-up must still be seen, see near_limit) and, for t >= 0 intersections, is not entirely behind
-      // the origin.  key = a lower bound of the entry time in f32 (what the stack keeps), +inf for a child not to be visited.
-      const double lim = near_limit(T.limit);
       const bool all_t = in_mode<MS>(T, M_CONTAINERS);
-      float key[RT_NODE_WIDTH];
-      uint32_t ref[RT_NODE_WIDTH];
-      double tmin[RT_NODE_WIDTH], tmax[RT_NODE_WIDTH];
-      bool hit[RT_NODE_WIDTH];
+      double ent[4];
       if (__builtin_amdgcn_ballot_w64(T.odd != 0u) == 0ull) {  // wave-uniform: a real branch
-        for (int c = 0; c < RT_NODE_WIDTH; c++) {
-          double bb[6];
-          for (int k = 0; k < 6; k++) bb[k] = node_box_value(raw, c, k);
-          hit[c] = box_times_finite(bb, T.o, T.dinv, tmin[c], tmax[c]);
+        const float floorv = all_t ? -INFINITY : 0.f;
+        for (int c = 0; c < 4; c++) {
+          uint32_t ref = raw[24 + c];
+          if (STATS && ref != RT_FREF_NONE) cnt.node_visits++;
+          ent[c] = pack_entry(ref, box_key_f32(T, raw, c, floorv, ref));
         }
       } else {  // some lane's ray is parallel to an axis: the reference's operand order decides what 0 * inf does
-        for (int c = 0; c < RT_NODE_WIDTH; c++) {
-          double bb[6];
-          for (int k = 0; k < 6; k++) bb[k] = node_box_value(raw, c, k);
-          hit[c] = box_times(bb, T.o, T.dinv, tmin[c], tmax[c]);
+        for (int c = 0; c < 4; c++) {
+          uint32_t ref = raw[24 + c];
+          if (STATS && ref != RT_FREF_NONE) cnt.node_visits++;
+          ent[c] = pack_entry(ref, box_key_f64<MS>(T, raw, c, all_t, ref));
         }
       }
-      for (int c = 0; c < RT_NODE_WIDTH; c++) {
-        ref[c] = raw[(RT_NODE_F64 ? 12 : 6) * RT_NODE_WIDTH + c];
-        // (& and |, not && and ||: four straight-line selects instead of four branches)
-        bool h = hit[c] & !(tmin[c] > lim) & (ref[c] != RT_FREF_NONE) & (all_t | !(tmax[c] < 0.));
-        if (STATS && ref[c] != RT_FREF_NONE) cnt.node_visits++;
-        float k = key_below(tmin[c]);
-        key[c] = h ? k : INFINITY;
-      }
-      // nearest child first: sort the four (key, ref) pairs ascending (5 compare-exchanges)
-#define RT_CSWAP(a, b)                                   \
-  {                                                      \
-    bool sw = key[b] < key[a];                           \
-    float ka = sw ? key[b] : key[a], kb = sw ? key[a] : key[b]; \
-    uint32_t ra = sw ? ref[b] : ref[a], rb = sw ? ref[a] : ref[b]; \
-    key[a] = ka; key[b] = kb; ref[a] = ra; ref[b] = rb;  \
+      if (MS != MS_SHADOW || RT_SHADOW_SORT) {
+        // nearest child first: sort the four entries ascending by key (5 compare-exchanges).  An entry read as an f64 is a
+        // positive normal number whose order is the order of (key, ref) as a u64, so an exchange is v_min_f64 + v_max_f64.
+#define RT_CSWAP(a, b)                            \
+  {                                               \
+    double lo_ = min_f64(ent[a], ent[b]), hi_ = max_f64(ent[a], ent[b]); \
+    ent[a] = lo_;                                 \
+    ent[b] = hi_;                                 \
   }
-      RT_CSWAP(0, 1)
-#if RT_NODE_WIDTH == 4
-      RT_CSWAP(2, 3)
-      RT_CSWAP(0, 2)
-      RT_CSWAP(1, 3)
-      RT_CSWAP(1, 2)
-#endif
+        RT_CSWAP(0, 1)
+        RT_CSWAP(2, 3)
+        RT_CSWAP(0, 2)
+        RT_CSWAP(1, 3)
+        RT_CSWAP(1, 2)
 #undef RT_CSWAP
-      if (key[0] < INFINITY) {
-        for (int c = RT_NODE_WIDTH - 1; c > 0; c--)  // farthest deepest
-          if (key[c] < INFINITY) stack_push(T, lds, ovf, ref[c], key[c], cnt);
-        T.cur = ref[0];
+        if (entry_key(ent[0]) < RT_KEY_NONE) {
+          for (int c = 3; c > 0; c--)  // farthest deepest
+            if (entry_key(ent[c]) < RT_KEY_NONE) stack_push(T, lds, ovf, ent[c]);
+          T.cur = entry_ref(ent[0]);
+        } else {
+          T.cur = stack_pop(T, lds, ovf);
+        }
       } else {
-        T.cur = stack_pop(T, lds, ovf);
+        // slot order: the first child to visit becomes current, the others are pushed
+        double nxt = pack_entry(RT_FREF_NONE, RT_KEY_NONE);
+        for (int c = 3; c >= 0; c--) {
+          if (entry_key(ent[c]) < RT_KEY_NONE) {
+            if (entry_key(nxt) < RT_KEY_NONE) stack_push(T, lds, ovf, nxt);
+            nxt = ent[c];
+          }
+        }
+        T.cur = entry_key(nxt) < RT_KEY_NONE ? entry_ref(nxt) : stack_pop(T, lds, ovf);
       }
     }
     unsigned long long tc1 = (STATS && min_active) ? (unsigned long long)clock64() : 0ull;
     if (STATS && min_active && first_active_lane()) cnt.cyc_trav += (uint32_t)((tc1 - tc0) >> 6);
-    const uint32_t leaf = RT_SPECULATE ? T.pending : T.cur;
+    const uint32_t leaf = T.cur;
     if (leaf == RT_FREF_NONE) break;
+#if RT_NODE_BREAK
+    if ((leaf >> RT_FREF_KIND_SHIFT) == RT_FREF_INNER) continue;
+#endif
     // ---- leaf ----
     if (STATS) count_step(cnt);
     uint32_t kind = leaf >> RT_FREF_KIND_SHIFT;
     uint32_t count = (leaf >> RT_FREF_COUNT_SHIFT) & RT_FREF_COUNT_MASK, first = leaf & RT_FREF_INDEX_MASK;
     if (kind == RT_FREF_TRIS) {
+      // A triangle's whole 80-B record is fetched in one go (the compiler would fetch p1 only after the determinant test: a
+      // second round trip), and the NEXT triangle of the run is fetched before this one is tested, so that a run of k
+      // triangles costs one exposed memory round trip instead of k.
+      const double2* tp = reinterpret_cast<const double2*>(s.tri_isect + (size_t)first * RT_TRI_STRIDE);
+      double2 r0 = tp[0], r1 = tp[1], r2 = tp[2], r3 = tp[3], r4 = tp[4];
       for (uint32_t j = 0; j < count; j++) {
-        // the whole 80-B record in one go (the compiler would fetch p1 only after the determinant test: a second round trip)
-        const double2* tp = reinterpret_cast<const double2*>(s.tri_isect + (size_t)(first + j) * RT_TRI_STRIDE);
-        double2 r0 = tp[0], r1 = tp[1], r2 = tp[2], r3 = tp[3], r4 = tp[4];
+        double2 n0 = r0, n1 = r1, n2 = r2, n3 = r3, n4 = r4;
+        if (j + 1 < count) {
+          tp += 5;
+          n0 = tp[0];
+          n1 = tp[1];
+          n2 = tp[2];
+          n3 = tp[3];
+          n4 = tp[4];
+        }
+#ifndef RT_HOST_EMU
+        asm volatile("" ::: "memory");  // the loads above are issued here, before the test below
+#endif
         pin_loaded(r0, r1, r2, r3, r4);
         const double tri[RT_TRI_STRIDE] = {r0.x, r0.y, r1.x, r1.y, r2.x, r2.y, r3.x, r3.y, r4.x, r4.y};
         double t, u, v;
@@ -398,6 +485,11 @@ __device__ __forceinline__ void trav_run(const DevScene& s, Trav& T, uint2* lds,
           uint32_t material = in_mode<MS>(T, M_SHADOW) ? s.prim_info[prim].y : 0u;
           add_roots<STATS, MS>(s, T, prim, material, 1, &t, u, v);
         }
+        r0 = n0;
+        r1 = n1;
+        r2 = n2;
+        r3 = n3;
+        r4 = n4;
       }
     } else {  // RT_FREF_PRIMS
       for (uint32_t j = 0; j < count; j++) {
@@ -427,11 +519,10 @@ __device__ __forceinline__ void trav_run(const DevScene& s, Trav& T, uint2* lds,
       }
     }
     if (STATS && min_active && first_active_lane()) cnt.cyc_adv += (uint32_t)(((unsigned long long)clock64() - tc1) >> 6);
-    if (RT_SPECULATE) T.pending = RT_FREF_NONE;
     if (in_mode<MS>(T, M_SHADOW) && T.a >= 1.) {  // min(intensity, 1) is already 1 (intersection.rs:124-126)
       T.cur = RT_FREF_NONE;
       T.sp = 0;
-    } else if (!RT_SPECULATE) {
+    } else {
       T.cur = stack_pop(T, lds, ovf);
     }
   }
@@ -520,7 +611,6 @@ __device__ __forceinline__ void run_machine(const DevScene& s, const DevOptions&
   Frame frames[RT_FRAMES];
   Trav T;
   T.cur = RT_FREF_NONE;
-  T.pending = RT_FREF_NONE;
   T.sp = 0;
   T.mode = M_CLOSEST;
   T.limit = 0.;

@@ -311,7 +311,6 @@ __global__ __launch_bounds__(64, RT_CLOSEST_WAVES) void trace_closest_kernel(Dev
   const double* __restrict__ queue = w.rays[level & 1];
   fast::Trav T;
   T.cur = RT_FREF_NONE;
-  T.pending = RT_FREF_NONE;
   T.sp = 0;
   T.mode = fast::M_CLOSEST;
   T.limit = 0.;
@@ -681,7 +680,6 @@ __global__ __launch_bounds__(64, RT_TRACE_WAVES) void trace_shadow_kernel(DevSce
   const size_t cap = w.cap_nodes;
   fast::Trav T;
   T.cur = RT_FREF_NONE;
-  T.pending = RT_FREF_NONE;
   T.sp = 0;
   T.mode = fast::M_SHADOW;
   T.limit = 0.;

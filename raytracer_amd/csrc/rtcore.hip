@@ -504,10 +504,6 @@ struct FastLayout {
 
 // The reference's f64 box, rounded outward to the node's f32 fields (min down, max up): a superset of the box.
 void set_node_box(DevNode& n, int child, const double* bb) {
-#if RT_NODE_F64
-  for (int k = 0; k < 6; k++) n.bb[child][k] = bb[k];
-  return;
-#endif
   for (int k = 0; k < 6; k++) {
     float f = (float)bb[k];
     if (k < 3) {
