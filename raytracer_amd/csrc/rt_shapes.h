@@ -215,18 +215,89 @@ __device__ __forceinline__ int analytic_roots(uint32_t shape, uint32_t flags, co
   }
 }
 
-#define RT_CSG_LIST_MAX 16   // hits kept per outermost CSG evaluation
+#define RT_CSG_LIST_MAX 16   // hits kept per outermost CSG evaluation (rt_scene_create bounds the worst case of every CSG object by it)
 #define RT_CSG_NEST_MAX 4    // nested CSG objects
+#define RT_CSG_GROUP_STACK 16  // traversal stack of a group that is a CSG operand
 
 // ---------------------------------------------------------------------------------------------
-// CSG: CsgObject::intersect (csg.rs:112-122).  Children are primitives or nested CSG objects
-// (groups inside CSG are rejected at scene creation).  Iterative over an explicit frame stack; the
-// hit list doubles as the nested collectors: a child CSG's survivors stay in place for its parent.
+// CSG: CsgObject::intersect (csg.rs:112-122).  Children are primitives, nested CSG objects, or groups of primitives
+// (a CSG object below a group below a CSG object is rejected at scene creation).  Iterative over an explicit frame stack;
+// the hit list doubles as the nested collectors: a child CSG's survivors stay in place for its parent.
+// Every level's temporary collector (IntersectionCollector::new(None, false), csg.rs:113) keeps all intersections and
+// tracks its closest positive t (intersection.rs:65-77): that is what prunes the walk through a group operand
+// (group.rs:182), so intersections deep inside a grouped operand can be missing from the list exactly as in the reference.
 // ---------------------------------------------------------------------------------------------
 struct CsgHit {
   double t, u, v;
   uint32_t prim;
 };
+
+// One primitive's roots -> the level's collector: list[n..) and its closest positive t.
+template <bool STATS>
+__device__ __forceinline__ void csg_add_prim(const DevScene& s, uint32_t idx, d3 o, d3 d, d3 dinv, CsgHit* list, int& n, double& hit_time,
+                                             Counters& cnt) {
+  double ts[4], u, v;
+  int k = prim_roots<STATS>(s, s.prim_info[idx], o, d, dinv, ts, u, v, cnt);
+  for (int i = 0; i < k; i++) {
+    if (sign_positive(ts[i]) && ts[i] < hit_time) hit_time = ts[i];
+    if (n < RT_CSG_LIST_MAX) {
+      list[n].t = ts[i];
+      list[n].u = u;
+      list[n].v = v;
+      list[n].prim = idx;
+      n++;
+    } else {
+      cnt.overflow = 1;
+    }
+  }
+}
+
+// ObjectGroup::intersect_iter (group.rs:171-201) for a group that is a CSG operand, into the level's collector.
+// `entry`: the group's DevEntry (rt_scene_create appends one per group operand).
+template <bool STATS>
+__device__ __forceinline__ void csg_add_group(const DevScene& s, uint32_t entry, d3 o, d3 d, d3 dinv, CsgHit* list, int& n,
+                                              double& hit_time, Counters& cnt) {
+  uint32_t stk_begin[RT_CSG_GROUP_STACK], stk_count[RT_CSG_GROUP_STACK];
+  double stk_t[RT_CSG_GROUP_STACK];
+  int sp = 0;
+  {
+    const DevEntry* root = s.entries + entry;
+    double bb[6], t;
+    for (int k = 0; k < 6; k++) bb[k] = root->bb[k];
+    if (STATS) cnt.node_visits++;
+    if (!bbox_time(bb, o, dinv, t)) return;
+    stk_begin[0] = root->begin;
+    stk_count[0] = root->count;
+    stk_t[0] = t;
+    sp = 1;
+  }
+  while (sp > 0) {
+    sp--;
+    if (stk_t[sp] >= hit_time) continue;
+    uint32_t begin = stk_begin[sp], count = stk_count[sp];
+    for (uint32_t i = count; i-- > 0;) {
+      const DevEntry* e = s.entries + (size_t)(begin + i);
+      uint32_t ref = e->ref, kind = ref >> RT_REF_KIND_SHIFT, idx = ref & RT_REF_INDEX_MASK;
+      if (kind == RT_REF_NODE) {
+        double bb[6], t;
+        for (int k = 0; k < 6; k++) bb[k] = e->bb[k];
+        if (STATS) cnt.node_visits++;
+        if (bbox_time(bb, o, dinv, t)) {
+          if (sp < RT_CSG_GROUP_STACK) {
+            stk_begin[sp] = e->begin;
+            stk_count[sp] = e->count;
+            stk_t[sp] = t;
+            sp++;
+          } else {
+            cnt.overflow = 1;  // (cannot happen: rt_scene_create checks the nesting of group operands)
+          }
+        }
+      } else if (kind == RT_REF_PRIM) {
+        csg_add_prim<STATS>(s, idx, o, d, dinv, list, n, hit_time, cnt);
+      }  // (a CSG object here is rejected by rt_scene_create)
+    }
+  }
+}
 
 // Fills list[0..n) with the surviving intersections of the outermost CSG object `csg_root`, ascending t.
 template <bool STATS>
@@ -234,10 +305,12 @@ __device__ __forceinline__ int csg_survivors(const DevScene& s, uint32_t csg_roo
   uint32_t f_csg[RT_CSG_NEST_MAX];
   uint8_t f_stage[RT_CSG_NEST_MAX];
   uint8_t f_start[RT_CSG_NEST_MAX];
+  double f_hit[RT_CSG_NEST_MAX];  // hit_time() of the level's temporary collector
   int n = 0, fp = 0;
   f_csg[0] = csg_root;
   f_stage[0] = 0;
   f_start[0] = 0;
+  f_hit[0] = INFINITY;
   while (fp >= 0) {
     uint32_t csg = f_csg[fp];
     if (f_stage[fp] < 2) {
@@ -245,24 +318,15 @@ __device__ __forceinline__ int csg_survivors(const DevScene& s, uint32_t csg_roo
       f_stage[fp]++;
       uint32_t kind = ref >> RT_REF_KIND_SHIFT, idx = ref & RT_REF_INDEX_MASK;
       if (kind == RT_REF_PRIM) {
-        double ts[4], u, v;
-        int k = prim_roots<STATS>(s, s.prim_info[idx], o, d, dinv, ts, u, v, cnt);
-        for (int i = 0; i < k; i++) {
-          if (n < RT_CSG_LIST_MAX) {
-            list[n].t = ts[i];
-            list[n].u = u;
-            list[n].v = v;
-            list[n].prim = idx;
-            n++;
-          } else {
-            cnt.overflow = 1;
-          }
-        }
+        csg_add_prim<STATS>(s, idx, o, d, dinv, list, n, f_hit[fp], cnt);
+      } else if (kind == RT_REF_NODE) {  // idx: the operand's DevEntry
+        csg_add_group<STATS>(s, idx, o, d, dinv, list, n, f_hit[fp], cnt);
       } else if (kind == RT_REF_CSG && fp + 1 < RT_CSG_NEST_MAX) {
         fp++;
         f_csg[fp] = idx;
         f_stage[fp] = 0;
         f_start[fp] = (uint8_t)n;
+        f_hit[fp] = INFINITY;
       }
       continue;
     }
@@ -294,6 +358,9 @@ __device__ __forceinline__ int csg_survivors(const DevScene& s, uint32_t csg_roo
     }
     n = w;
     fp--;
+    if (fp >= 0)  // the survivors are push()ed to the parent's collector (csg.rs:119-121)
+      for (int i = start; i < n; i++)
+        if (sign_positive(list[i].t) && list[i].t < f_hit[fp]) f_hit[fp] = list[i].t;
   }
   return n;
 }

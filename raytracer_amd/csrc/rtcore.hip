@@ -237,6 +237,29 @@ int fail(int code, const std::string& msg) {
       return fail(RT_ERR_DEVICE, std::string(#expr) + " failed: " + hipGetErrorString(_e));        \
   } while (0)
 
+// hipEvent_t that is destroyed on every path out of its scope.
+struct Event {
+  hipEvent_t e = nullptr;
+  Event() = default;
+  Event(const Event&) = delete;
+  Event& operator=(const Event&) = delete;
+  ~Event() {
+    if (e) (void)hipEventDestroy(e);
+  }
+  hipError_t create() { return hipEventCreate(&e); }
+};
+// Device allocation that is freed on every path out of its scope.
+struct DeviceBuffer {
+  void* p = nullptr;
+  DeviceBuffer() = default;
+  DeviceBuffer(const DeviceBuffer&) = delete;
+  DeviceBuffer& operator=(const DeviceBuffer&) = delete;
+  ~DeviceBuffer() {
+    if (p) (void)hipFree(p);
+  }
+  hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 16); }
+};
+
 // Device memory that scenes hand back when they are destroyed, kept for the next scene on the same device: an
 // animation creates and destroys one rt_scene per frame (a scene table arena and a render workspace each), and
 // hipMalloc / hipFree cost milliseconds and synchronise the device.  Bounded: at most 24 blocks and 96 GiB
@@ -357,6 +380,41 @@ struct StageBuffer {
   ~StageBuffer() { std::free(p); }
 };
 
+// What frames of one kind of scene taught about the batch layout (nodes_per_sample, ratio_floor), kept per device and scene
+// shape for the scenes to come: an animation (or the one-shot rt_render, which is what the reference-side hook calls,
+// renderer.rs:68-98) makes a new rt_scene per frame, and every new scene would otherwise start from 3 node records per
+// sample again (the 4K bench frame: two batches instead of one).  A wrong guess costs time, never pixels (fallback_kernel).
+struct LearnedLayout {
+  struct Entry {
+    int device;
+    uint64_t shape;
+    uint32_t nodes_per_sample, ratio_floor;
+  };
+  std::mutex mu;
+  std::vector<Entry> entries;  // most recent last, at most 16
+  bool lookup(int device, uint64_t shape, uint32_t* nodes_per_sample, uint32_t* ratio_floor) {
+    std::lock_guard<std::mutex> lock(mu);
+    for (const Entry& e : entries)
+      if (e.device == device && e.shape == shape) {
+        *nodes_per_sample = e.nodes_per_sample;
+        *ratio_floor = e.ratio_floor;
+        return true;
+      }
+    return false;
+  }
+  void remember(int device, uint64_t shape, uint32_t nodes_per_sample, uint32_t ratio_floor) {
+    std::lock_guard<std::mutex> lock(mu);
+    for (size_t i = 0; i < entries.size(); i++)
+      if (entries[i].device == device && entries[i].shape == shape) {
+        entries.erase(entries.begin() + (long)i);
+        break;
+      }
+    if (entries.size() >= 16) entries.erase(entries.begin());
+    entries.push_back({device, shape, nodes_per_sample, ratio_floor});
+  }
+};
+LearnedLayout g_learned;
+
 struct rt_scene {
   DevScene dev;
   // every scene table, the statistics counters and the summary word live in ONE device block (rt_scene_create)
@@ -382,6 +440,8 @@ struct rt_scene {
   // fallback kernel (same pixels, slower); the count of such events comes back with every frame and doubles this.
   mutable uint32_t nodes_per_sample = 3;
   mutable uint32_t ratio_floor = 1;  // smallest ratio worth trying again (one more than the last that overflowed)
+  mutable bool layout_learned = false;  // a frame of this scene has reported back (absorb_summary)
+  uint64_t shape = 0;                   // what g_learned files this scene under
   mutable uint32_t* d_summary = nullptr;  // [0] fallback flags of the frame in flight, [1] / [2] node records / rays of a level used per sample, x 16
   mutable uint32_t* h_summary = nullptr;  // pinned copy, valid once summary_event has completed
   mutable hipEvent_t summary_event = nullptr;
@@ -394,6 +454,7 @@ struct rt_scene {
     // the blocks go back to the pool, for other scenes to use at once: first wait for this scene's own GPU work
     if (rendered && done_event) (void)hipEventSynchronize(done_event);
     if (summary_pending && summary_event) (void)hipEventSynchronize(summary_event);
+    if (layout_learned) g_learned.remember(device, shape, nodes_per_sample, ratio_floor);
     g_device_pool.give(ws_base, ws_bytes, device);
     g_device_pool.give(arena, arena_cap, device);
     g_pinned_slots.give(h_summary);
@@ -553,6 +614,18 @@ void assign_ranks(const rt_scene_desc* d, std::vector<uint32_t>& rank) {
             uint32_t ck = cr >> RT_REF_KIND_SHIFT, ci = cr & RT_REF_INDEX_MASK;
             if (ck == RT_REF_PRIM) rank[ci] = r;
             else if (ck == RT_REF_CSG) csg_stack.push_back(ci);
+            else {  // a group operand: every primitive below it (check_graph: no CSG objects there)
+              std::vector<uint32_t> groups{ci};
+              while (!groups.empty()) {
+                uint32_t gg = groups.back();
+                groups.pop_back();
+                for (uint32_t k = d->node_child_begin[gg]; k < d->node_child_begin[gg + 1]; k++) {
+                  uint32_t gr = d->child_ref[k], gk = gr >> RT_REF_KIND_SHIFT, gi = gr & RT_REF_INDEX_MASK;
+                  if (gk == RT_REF_PRIM) rank[gi] = r;
+                  else if (gk == RT_REF_NODE) groups.push_back(gi);
+                }
+              }
+            }
           }
         }
       }
@@ -760,6 +833,76 @@ bool build_fast_layout(const rt_scene_desc* d, FastLayout& L) {
   return true;
 }
 
+
+// Most roots one primitive can add to a collector (sphere.rs:27-34, plane.rs:13-19, cube.rs:25-42, cylinder.rs:54-120,
+// cone.rs:56-127, triangle.rs:48-71): what bounds a CSG object's hit list.
+uint32_t max_roots(const rt_scene_desc* d, uint32_t prim) {
+  switch (d->prim_shape[prim]) {
+    case RT_SHAPE_PLANE:
+    case RT_SHAPE_TRIANGLE:
+    case RT_SHAPE_SMOOTH_TRIANGLE: return 1;
+    case RT_SHAPE_CYLINDER:
+    case RT_SHAPE_CONE: return d->quadric_closed[d->prim_geom[prim]] ? 4 : 2;
+    default: return 2;
+  }
+}
+
+// The object graph reachable from the root must be a tree (the reference's objects own their children): no reference
+// back to an ancestor — the layout passes below recurse over it —, nothing referenced twice.  Also checked here, because
+// they need the same walk: csg_depth is the real CSG nesting; what the device's CSG evaluation is bounded by
+// (RT_CSG_LIST_MAX roots per outermost CSG object in the worst case, so a render can never overflow its hit list; group
+// operands of at most RT_CSG_GROUP_STACK pending sub-groups, with no CSG object inside them).  Iterative: the input may be
+// arbitrarily deep, and nothing may overflow the host stack on behalf of a malformed scene.
+int check_graph(const rt_scene_desc* d) {
+  const uint32_t N = d->n_nodes, C = d->n_csgs;
+  std::vector<uint8_t> seen(N + C, 0);  // 0 not visited, 1 on the current path, 2 done
+  struct Frame {
+    uint32_t v, next, csg_depth;
+    bool in_csg, in_csg_group;
+    uint64_t roots;  // worst-case roots of the primitives below (kept inside CSG objects only)
+  };
+  std::vector<Frame> path;
+  auto n_children = [&](uint32_t v) { return v < N ? d->node_child_begin[v + 1] - d->node_child_begin[v] : 2u; };
+  auto child = [&](uint32_t v, uint32_t k) { return v < N ? d->child_ref[d->node_child_begin[v] + k] : (k == 0 ? d->csg_left[v - N] : d->csg_right[v - N]); };
+  seen[0] = 1;
+  path.push_back({0u, 0u, 0u, false, false, 0ull});
+  while (!path.empty()) {
+    Frame& f = path.back();
+    if (f.next == n_children(f.v)) {
+      Frame done = f;
+      seen[done.v] = 2;
+      path.pop_back();
+      if (done.v >= N && done.csg_depth == 0 && done.roots > RT_CSG_LIST_MAX)
+        return fail(RT_ERR_UNSUPPORTED, "a CSG object can produce " + std::to_string(done.roots) + " intersections per ray; the device keeps " +
+                                            std::to_string(RT_CSG_LIST_MAX) + " (RT_CSG_LIST_MAX)");
+      if (!path.empty() && path.back().in_csg) path.back().roots += done.roots;
+      continue;
+    }
+    uint32_t ref = child(f.v, f.next++), kind = ref >> RT_REF_KIND_SHIFT, idx = ref & RT_REF_INDEX_MASK;
+    if (kind == RT_REF_PRIM) {
+      if (f.in_csg) f.roots += max_roots(d, idx);
+      continue;
+    }
+    uint32_t u = kind == RT_REF_NODE ? idx : N + idx;
+    if (seen[u] == 1) return fail(RT_ERR_INVALID_ARGUMENT, "the object graph has a cycle (a group or CSG object contains itself)");
+    if (seen[u] == 2) return fail(RT_ERR_INVALID_ARGUMENT, "a group or CSG object is referenced more than once");
+    Frame g = {u, 0u, f.csg_depth, f.in_csg, f.in_csg_group, 0ull};
+    if (kind == RT_REF_CSG) {
+      if (f.in_csg_group)
+        return fail(RT_ERR_UNSUPPORTED, "a CSG object inside a group that is a CSG operand is not supported on the device");
+      if (d->csg_depth[idx] != (f.in_csg ? f.csg_depth + 1 : 0u))
+        return fail(RT_ERR_INVALID_ARGUMENT, "csg_depth does not match the nesting of the CSG objects");
+      g.csg_depth = d->csg_depth[idx];
+      g.in_csg = true;
+    } else if (f.in_csg) {
+      g.in_csg_group = true;
+    }
+    seen[u] = 1;
+    path.push_back(g);  // (f is dangling from here on)
+  }
+  return RT_OK;
+}
+
 int validate(const rt_scene_desc* d) {
   if (!d) return fail(RT_ERR_INVALID_ARGUMENT, "scene is NULL");
   if (d->abi_version != RT_ABI_VERSION) return fail(RT_ERR_INVALID_ARGUMENT, "rt_scene_desc.abi_version mismatch");
@@ -803,11 +946,8 @@ int validate(const rt_scene_desc* d) {
     if (!ref_ok(d, d->csg_left[i]) || !ref_ok(d, d->csg_right[i])) return fail(RT_ERR_INVALID_ARGUMENT, "csg child out of range");
     if (d->csg_depth[i] >= RT_CSG_NEST_MAX)
       return fail(RT_ERR_UNSUPPORTED, "CSG objects nested deeper than RT_CSG_NEST_MAX (4) are not supported on the device");
-    for (uint32_t ref : {d->csg_left[i], d->csg_right[i]})
-      if ((ref >> RT_REF_KIND_SHIFT) == RT_REF_NODE)
-        return fail(RT_ERR_UNSUPPORTED, "a group as a CSG operand is not supported on the device (primitives and nested CSG are)");
   }
-  return RT_OK;
+  return check_graph(d);
 }
 
 DevOptions dev_options(const rt_options* o) {
@@ -896,6 +1036,7 @@ size_t carve_workspace(stream::Ws* w, char* base, uint64_t n, uint32_t ratio, ui
 void absorb_summary(const rt_scene* sc) {
   if (!sc->summary_pending || hipEventQuery(sc->summary_event) != hipSuccess) return;
   sc->summary_pending = false;
+  sc->layout_learned = true;
   if (sc->h_summary[0] > 0) {
     sc->ratio_floor = std::min<uint32_t>(sc->nodes_per_sample + 1u, RT_STREAM_RATIO_MAX);  // this ratio was too small once
     if (sc->nodes_per_sample < RT_STREAM_RATIO_MAX) sc->nodes_per_sample *= 2;
@@ -932,6 +1073,7 @@ int ensure_workspace(const rt_scene* sc, uint64_t want_samples, uint32_t* batch_
   }
   // node ids carry two flag bits, and (node, light) items are counted in 32 bits
   limit = std::min<uint64_t>(limit, std::min<uint64_t>((1ull << 30) / ratio, ((1ull << 32) - 1) / ((uint64_t)ratio * std::max<uint32_t>(sc->n_lights, 1u))));
+  limit = std::max<uint64_t>(limit & ~63ull, 64);  // (rounding n UP to 64 below must not carry it past the limit)
   uint64_t n = std::max<uint64_t>(align_up(std::min<uint64_t>(want_samples, limit), 64), 64);
   size_t need = carve_workspace(nullptr, nullptr, n, ratio, sc->n_lights);
   if (need > sc->ws_bytes) {
@@ -1009,8 +1151,8 @@ struct TimedLaunch {  // records an event before and after one launch when the s
 #define RT_RETRACE_BLOCKS_PER_CU 16u  // few rays, long dependent walks: 4 -> 16 blocks per CU took 1.85 -> 1.35 ms off the 4K frame
 #endif
 template <bool CAMERA, bool STATS>
-int run_stream_batch(const rt_scene* sc, const rt_camera& cam, const DevOptions& dopt, const stream::Batch& b, hipStream_t st) {
-  const stream::Ws& w = sc->ws;
+int run_stream_batch(const rt_scene* sc, const stream::Ws& w, const rt_camera& cam, const DevOptions& dopt, const stream::Batch& b,
+                     hipStream_t st) {
   const uint32_t trace_grid = (uint32_t)sc->n_cus * 4u * RT_TRACE_WAVES, closest_grid = (uint32_t)sc->n_cus * 4u * RT_CLOSEST_WAVES;
   const uint32_t wide_grid = (uint32_t)sc->n_cus * 8u;
   uint32_t need = (b.n_samples + 255u) / 256u;
@@ -1055,15 +1197,13 @@ int run_stream_batch(const rt_scene* sc, const rt_camera& cam, const DevOptions&
   return RT_OK;
 }
 
+// The frame's part in batches of at most batch_samples samples through workspace w (laid out for that many).
 template <bool STATS>
-int launch_stream_render(const rt_scene* sc, const rt_camera* cam, const DevOptions& dopt, uint32_t part, uint32_t n_parts,
-                         uint32_t tiles_x, uint32_t n_owned, int packed, double* d_out, hipStream_t st) {
+int stream_render_with(const rt_scene* sc, const stream::Ws& w, uint32_t batch_samples, const rt_camera* cam, const DevOptions& dopt,
+                       uint32_t part, uint32_t n_parts, uint32_t tiles_x, uint32_t n_owned, int packed, double* d_out, hipStream_t st) {
   const uint32_t n2 = dopt.n_offsets * dopt.n_offsets, per_tile = 64u * n2;
-  uint32_t batch_samples = 0;
-  int rc = ensure_workspace(sc, (uint64_t)n_owned * per_tile, &batch_samples);
-  if (rc) return rc;
   const uint32_t tiles_per_batch = std::max(1u, batch_samples / per_tile);
-  if (tiles_per_batch * per_tile > sc->ws_samples) return fail(RT_ERR_DEVICE, "render workspace smaller than one tile");
+  if (tiles_per_batch * per_tile > batch_samples) return fail(RT_ERR_DEVICE, "render workspace smaller than one tile");
   for (uint32_t tile0 = 0; tile0 < n_owned; tile0 += tiles_per_batch) {
     stream::Batch b;
     b.part = part;
@@ -1076,17 +1216,29 @@ int launch_stream_render(const rt_scene* sc, const rt_camera* cam, const DevOpti
     b.n_samples = b.n_tiles * per_tile;
     b.packed = (uint32_t)packed;
     b.given_o = b.given_d = nullptr;
-    b.tile_xy = sc->ws.tile_xy;
+    b.tile_xy = w.tile_xy;
     b.n2_magic = (1ull << 32) / n2 + 1;
     hipLaunchKernelGGL(stream::tile_table_kernel, dim3(std::max(1u, std::min(1024u, (b.n_tiles + 255u) / 256u))), dim3(256), 0, st, b,
-                       sc->ws.tile_xy);
-    rc = run_stream_batch<true, STATS>(sc, *cam, dopt, b, st);
+                       w.tile_xy);
+    int rc = run_stream_batch<true, STATS>(sc, w, *cam, dopt, b, st);
     if (rc) return rc;
     uint32_t grid = std::max(1u, std::min((uint32_t)sc->n_cus * 8u, (b.n_tiles * 64u + 255u) / 256u));
     TimedLaunch t(sc, st, TC_OTHER);
-    hipLaunchKernelGGL(stream::resolve_kernel, dim3(grid), dim3(256), 0, st, *cam, sc->ws, b, d_out);
+    hipLaunchKernelGGL(stream::resolve_kernel, dim3(grid), dim3(256), 0, st, *cam, w, b, d_out);
   }
   HIP_TRY(hipGetLastError());
+  return RT_OK;
+}
+
+template <bool STATS>
+int launch_stream_render(const rt_scene* sc, const rt_camera* cam, const DevOptions& dopt, uint32_t part, uint32_t n_parts,
+                         uint32_t tiles_x, uint32_t n_owned, int packed, double* d_out, hipStream_t st) {
+  const uint32_t per_tile = 64u * dopt.n_offsets * dopt.n_offsets;
+  uint32_t batch_samples = 0;
+  int rc = ensure_workspace(sc, (uint64_t)n_owned * per_tile, &batch_samples);
+  if (rc) return rc;
+  rc = stream_render_with<STATS>(sc, sc->ws, batch_samples, cam, dopt, part, n_parts, tiles_x, n_owned, packed, d_out, st);
+  if (rc) return rc;
   return post_summary(sc, st);
 }
 
@@ -1100,12 +1252,12 @@ int launch_render_once(const rt_scene* scene, const rt_camera* cam, const rt_opt
   uint32_t n_tiles = tiles_total(cam->width, cam->height, &tiles_x);
   uint32_t n_owned = n_tiles > part ? (n_tiles - part + n_parts - 1) / n_parts : 0;
   HIP_TRY(hipMemsetAsync(scene->d_overflow, 0, sizeof(uint32_t), stream));
-  hipEvent_t e0 = nullptr, e1 = nullptr;
+  Event e0, e1;
   if (stats) {
     HIP_TRY(hipMemsetAsync(scene->d_stats, 0, RT_N_COUNTERS * sizeof(unsigned long long), stream));
-    HIP_TRY(hipEventCreate(&e0));
-    HIP_TRY(hipEventCreate(&e1));
-    HIP_TRY(hipEventRecord(e0, stream));
+    HIP_TRY(e0.create());
+    HIP_TRY(e1.create());
+    HIP_TRY(hipEventRecord(e0.e, stream));
   }
   if (n_owned) {
     DevOptions dopt = dev_options(opt);
@@ -1137,16 +1289,14 @@ int launch_render_once(const rt_scene* scene, const rt_camera* cam, const rt_opt
     HIP_TRY(hipEventRecord(scene->done_event, stream));
   }
   if (stats) {
-    HIP_TRY(hipEventRecord(e1, stream));
+    HIP_TRY(hipEventRecord(e1.e, stream));
     HIP_TRY(hipStreamSynchronize(stream));
     unsigned long long h[RT_N_COUNTERS];
     uint32_t ovf = 0;
     HIP_TRY(hipMemcpy(h, scene->d_stats, sizeof(h), hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(&ovf, scene->d_overflow, sizeof(ovf), hipMemcpyDeviceToHost));
     float ms = 0.f;
-    HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
-    (void)hipEventDestroy(e0);
-    (void)hipEventDestroy(e1);
+    HIP_TRY(hipEventElapsedTime(&ms, e0.e, e1.e));
     std::memset(stats, 0, sizeof(*stats));
     stats->rays_primary = h[0];
     stats->rays_shadow = h[1];
@@ -1249,6 +1399,23 @@ int rt_scene_create(const rt_scene_desc* d, rt_scene** out) {
     e.ref = d->child_ref[i];
     if ((e.ref >> RT_REF_KIND_SHIFT) == RT_REF_NODE) fill_node_fields(e, e.ref & RT_REF_INDEX_MASK);
   }
+  // a group that is a CSG operand (csg.rs:113-115) is walked from a record of its own, appended here; the device's CSG
+  // tables refer to it by RT_MAKE_REF(RT_REF_NODE, record index)
+  std::vector<uint32_t> dev_csg_left(d->csg_left, d->csg_left + d->n_csgs), dev_csg_right(d->csg_right, d->csg_right + d->n_csgs);
+  for (uint32_t i = 0; i < d->n_csgs; i++)
+    for (std::vector<uint32_t>* side : {&dev_csg_left, &dev_csg_right}) {
+      uint32_t ref = (*side)[i];
+      if ((ref >> RT_REF_KIND_SHIFT) != RT_REF_NODE) continue;
+      uint32_t g = ref & RT_REF_INDEX_MASK;
+      if (std::max(1u, stack_need(d, g, memo, 0)) > RT_CSG_GROUP_STACK)
+        return fail(RT_ERR_UNSUPPORTED, "a group that is a CSG operand nests deeper than the device walks it (RT_CSG_GROUP_STACK)");
+      DevEntry e;
+      std::memset(&e, 0, sizeof(e));
+      e.ref = ref;
+      fill_node_fields(e, g);
+      (*side)[i] = RT_MAKE_REF(RT_REF_NODE, (uint32_t)entries.size());
+      entries.push_back(e);
+    }
   FastLayout L;
   if (!build_fast_layout(d, L)) return fail(RT_ERR_UNSUPPORTED, L.error);
   if (L.stack_need > RT_FAST_STACK_MAX)
@@ -1350,8 +1517,8 @@ int rt_scene_create(const rt_scene_desc* d, rt_scene** out) {
   UPA(uint8_t, d->quadric_closed, d->n_quadrics, quadric_closed);
   UPA(uint8_t, d->csg_op, d->n_csgs, csg_op);
   UPA(uint8_t, d->csg_depth, d->n_csgs, csg_depth);
-  UPA(uint32_t, d->csg_left, d->n_csgs, csg_left);
-  UPA(uint32_t, d->csg_right, d->n_csgs, csg_right);
+  UP(dev_csg_left, csg_left);
+  UP(dev_csg_right, csg_right);
   UPA(double, d->material, (size_t)d->n_materials * RT_MAT_STRIDE, material);
   UPA(uint8_t, d->pattern_kind, d->n_materials, pattern_kind);
   UPA(double, d->pattern_c1, (size_t)d->n_materials * 3, pattern_c1);
@@ -1364,6 +1531,8 @@ int rt_scene_create(const rt_scene_desc* d, rt_scene** out) {
   sc->dev.n_lights = d->n_lights;
   sc->dev.n_prims = d->n_prims;
   sc->n_lights = d->n_lights;
+  sc->shape = ((uint64_t)d->n_prims << 40) ^ ((uint64_t)d->n_nodes << 20) ^ ((uint64_t)d->n_lights << 8) ^ (uint64_t)d->n_materials;
+  (void)g_learned.lookup(sc->device, sc->shape, &sc->nodes_per_sample, &sc->ratio_floor);
   if (const char* e = std::getenv("RT_STREAM_NODES_PER_SAMPLE")) {  // where the adaptive ratio starts (tests start it too low)
     unsigned long v = std::strtoul(e, nullptr, 10);
     if (v >= 1 && v <= RT_STREAM_RATIO_MAX) sc->nodes_per_sample = (uint32_t)v;
@@ -1436,10 +1605,11 @@ int rt_trace_rays(const rt_scene* scene, const rt_options* options, uint32_t n, 
   if (options->max_depth > RT_MAX_DEPTH) return fail(RT_ERR_UNSUPPORTED, "max_depth exceeds RT_MAX_DEPTH");
   if (n == 0) return RT_OK;
   size_t bytes = (size_t)n * 3 * sizeof(double);
-  double *d_o = nullptr, *d_d = nullptr, *d_c = nullptr;
-  HIP_TRY(hipMalloc((void**)&d_o, bytes));
-  HIP_TRY(hipMalloc((void**)&d_d, bytes));
-  HIP_TRY(hipMalloc((void**)&d_c, bytes));
+  DeviceBuffer b_o, b_d, b_c;
+  HIP_TRY(b_o.alloc(bytes));
+  HIP_TRY(b_d.alloc(bytes));
+  HIP_TRY(b_c.alloc(bytes));
+  double *d_o = (double*)b_o.p, *d_d = (double*)b_d.p, *d_c = (double*)b_c.p;
   int rc = RT_OK;
   do {
     if (hipMemcpy(d_o, origin, bytes, hipMemcpyHostToDevice) != hipSuccess || hipMemcpy(d_d, direction, bytes, hipMemcpyHostToDevice) != hipSuccess ||
@@ -1473,7 +1643,7 @@ int rt_trace_rays(const rt_scene* scene, const rt_options* options, uint32_t n, 
           rc = fail(RT_ERR_DEVICE, "hipMemsetAsync(colours) failed");
           break;
         }
-        rc = run_stream_batch<false, false>(scene, no_cam, dopt, b, 0);
+        rc = run_stream_batch<false, false>(scene, scene->ws, no_cam, dopt, b, 0);
         if (rc == RT_OK && hipMemcpyAsync(d_c + (size_t)at * 3, scene->ws.sample_rgb, (size_t)b.n_samples * 24, hipMemcpyDeviceToDevice, 0) != hipSuccess)
           rc = fail(RT_ERR_DEVICE, "copy of the traced colours failed");
       }
@@ -1487,50 +1657,59 @@ int rt_trace_rays(const rt_scene* scene, const rt_options* options, uint32_t n, 
     }
     if (ovf) rc = fail(RT_ERR_OVERFLOW, "a per-ray bounded list overflowed on the device");
   } while (0);
-  (void)hipFree(d_o);
-  (void)hipFree(d_d);
-  (void)hipFree(d_c);
   return rc;
 }
 
 int rt_render(const rt_scene_desc* scene_desc, const rt_camera* camera, const rt_options* options, double* out_rgb, rt_stats* stats) {
   if (!out_rgb || !camera) return fail(RT_ERR_INVALID_ARGUMENT, "out_rgb and camera are required");
-  hipEvent_t e0, e1, e2, e3;
-  HIP_TRY(hipEventCreate(&e0));
-  HIP_TRY(hipEventCreate(&e1));
-  HIP_TRY(hipEventCreate(&e2));
-  HIP_TRY(hipEventCreate(&e3));
-  HIP_TRY(hipEventRecord(e0, 0));
+  Event e0, e1, e2, e3;  // (destroyed on every path)
+  if (stats) {
+    HIP_TRY(e0.create());
+    HIP_TRY(e1.create());
+    HIP_TRY(e2.create());
+    HIP_TRY(e3.create());
+    HIP_TRY(hipEventRecord(e0.e, 0));
+  }
   rt_scene* sc = nullptr;
   int rc = rt_scene_create(scene_desc, &sc);
   if (rc) return rc;
-  HIP_TRY(hipEventRecord(e1, 0));
+  struct SceneGuard {
+    rt_scene* s;
+    ~SceneGuard() { rt_scene_destroy(s); }
+  } guard{sc};
+  if (stats) HIP_TRY(hipEventRecord(e1.e, 0));
+  // the image: a block of the device pool (an animation through this entry point renders frame after frame)
   size_t bytes = (size_t)camera->width * camera->height * 3 * sizeof(double);
-  double* d_out = nullptr;
-  if (hipMalloc((void**)&d_out, bytes ? bytes : 16) != hipSuccess) {
-    rt_scene_destroy(sc);
-    return fail(RT_ERR_DEVICE, "hipMalloc(image) failed");
-  }
+  struct PoolBlock {
+    void* p = nullptr;
+    size_t cap = 0;
+    int device = 0;
+    ~PoolBlock() { g_device_pool.give(p, cap, device); }
+  } image;
+  image.device = sc->device;
+  image.p = g_device_pool.take(bytes ? bytes : 16, sc->device, &image.cap);
+  if (!image.p) return fail(RT_ERR_DEVICE, "hipMalloc(image) failed");
+  // stats == NULL (what the reference-side hook passes): the production kernels, nothing synchronises before the download
   rt_stats local;
-  rc = launch_render(sc, camera, options, 0, 1, 0, d_out, 0, &local);
+  rc = launch_render(sc, camera, options, 0, 1, 0, (double*)image.p, 0, stats ? &local : nullptr);
   if (rc == RT_OK || rc == RT_ERR_OVERFLOW) {
-    (void)hipEventRecord(e2, 0);
-    if (hipMemcpy(out_rgb, d_out, bytes, hipMemcpyDeviceToHost) != hipSuccess) rc = fail(RT_ERR_DEVICE, "download of the image failed");
-    (void)hipEventRecord(e3, 0);
-    (void)hipEventSynchronize(e3);
-    float up = 0.f, down = 0.f;
-    (void)hipEventElapsedTime(&up, e0, e1);
-    (void)hipEventElapsedTime(&down, e2, e3);
-    local.ms_upload = up;
-    local.ms_download = down;
-    if (stats) *stats = local;
+    if (stats) (void)hipEventRecord(e2.e, 0);
+    if (hipMemcpy(out_rgb, image.p, bytes, hipMemcpyDeviceToHost) != hipSuccess) rc = fail(RT_ERR_DEVICE, "download of the image failed");
+    if (stats) {
+      (void)hipEventRecord(e3.e, 0);
+      (void)hipEventSynchronize(e3.e);
+      float up = 0.f, down = 0.f;
+      (void)hipEventElapsedTime(&up, e0.e, e1.e);
+      (void)hipEventElapsedTime(&down, e2.e, e3.e);
+      local.ms_upload = up;
+      local.ms_download = down;
+      *stats = local;
+    }
+  } else {
+    (void)hipStreamSynchronize(0);
   }
-  (void)hipFree(d_out);
-  rt_scene_destroy(sc);
-  (void)hipEventDestroy(e0);
-  (void)hipEventDestroy(e1);
-  (void)hipEventDestroy(e2);
-  (void)hipEventDestroy(e3);
+  // (the download has waited for the frame: its summary is in; ~rt_scene remembers what it says about this kind of scene)
+  absorb_summary(sc);
   return rc;
 }
 

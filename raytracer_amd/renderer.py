@@ -93,14 +93,15 @@ def quantize_device(d_rgb_ptr: int, n_values: int, d_out_ptr: int, stream: int =
     _check(N.core_lib().rt_quantize_device(C.c_void_p(d_rgb_ptr), n_values, C.c_void_p(d_out_ptr), C.c_void_p(stream)))
 
 
-def render(flat: FlatScene, camera: N.rt_camera, options: N.rt_options) -> Tuple[np.ndarray, dict]:
+def render(flat: FlatScene, camera: N.rt_camera, options: N.rt_options, want_stats: bool = True) -> Tuple[np.ndarray, Optional[dict]]:
     """`Renderer::render` (renderer.rs:75-98) minus compute_bvh (done by `flatten`): one `rt_render` call.
-    Returns (rgb[h, w, 3] f64, stats)."""
+    Returns (rgb[h, w, 3] f64, stats).  want_stats=False passes stats = NULL, which is the call the reference-side hook
+    makes (ffi/hook.rs): the production kernels, no counters."""
     out = np.zeros((camera.height, camera.width, 3), dtype=np.float64)
-    st = N.rt_stats()
+    st = N.rt_stats() if want_stats else None
     _check(N.core_lib().rt_render(C.byref(flat.desc), C.byref(camera), C.byref(options),
-                                  out.ctypes.data_as(C.POINTER(C.c_double)), C.byref(st)))
-    return out, st.as_dict()
+                                  out.ctypes.data_as(C.POINTER(C.c_double)), C.byref(st) if st is not None else None))
+    return out, (st.as_dict() if st is not None else None)
 
 
 def as_u8_rgb(rgb: np.ndarray) -> np.ndarray:

@@ -42,3 +42,75 @@ def test_ctypes_structs_match_the_header(tmp_path):
     subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
     sizes = [int(x) for x in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()]
     assert sizes == [ctypes.sizeof(N.rt_scene_desc), ctypes.sizeof(N.rt_camera), ctypes.sizeof(N.rt_options), ctypes.sizeof(N.rt_stats)]
+
+
+# ---- rt_scene_create rejects malformed or unsupported scenes before it touches a device (no GPU needed) --------------
+def _patched(flat, **arrays):
+    """A copy of flat.desc with some tables replaced (returns the desc and whatever keeps the new tables alive)."""
+    import numpy as np
+    from raytracer_amd import _native as N
+    d = N.rt_scene_desc()
+    ctypes.memmove(ctypes.byref(d), ctypes.byref(flat.desc), ctypes.sizeof(d))
+    keep = [flat]
+    for name, values in arrays.items():
+        field_type = dict(N.rt_scene_desc._fields_)[name]
+        a = np.ascontiguousarray(values, dtype={ctypes.c_double: np.float64, ctypes.c_uint32: np.uint32, ctypes.c_uint8: np.uint8}[field_type._type_])
+        keep.append(a)
+        setattr(d, name, a.ctypes.data_as(field_type))
+    return d, keep
+
+
+def _create(desc):
+    from raytracer_amd import _native as N
+    L = N.core_lib()
+    h = ctypes.c_void_p()
+    rc = L.rt_scene_create(ctypes.byref(desc), ctypes.byref(h))
+    assert not h.value or rc == 0
+    if rc == 0:
+        L.rt_scene_destroy(h)
+    return rc, L.rt_last_error().decode()
+
+
+def test_scene_graph_with_a_cycle_or_a_shared_group_is_rejected():
+    from conftest import N, S
+    sb = S.SceneBuilder()
+    sb.add_object(sb.group([sb.group([sb.primitive(N.SPHERE)]), sb.primitive(N.CUBE)]))
+    flat = sb.flatten(build_bvh=False)
+    refs = flat.array("child_ref").astype("uint32")
+    kinds = refs >> 30
+    group_slots = [i for i, k in enumerate(kinds) if k == N.RT_REF_NODE]
+    assert len(group_slots) >= 2
+    cyc = refs.copy()
+    cyc[group_slots[-1]] = (N.RT_REF_NODE << 30) | 0  # the innermost group reference now points back at the root
+    rc, msg = _create(_patched(flat, child_ref=cyc)[0])
+    assert rc == -1 and "cycle" in msg
+    shared = refs.copy()
+    shared[group_slots[-1]] = refs[group_slots[0]]     # the same group referenced from two places
+    rc, msg = _create(_patched(flat, child_ref=shared)[0])
+    assert rc == -1 and ("cycle" in msg or "more than once" in msg)
+
+
+def test_csg_limits_are_checked_at_scene_creation():
+    """The device keeps RT_CSG_LIST_MAX = 16 intersections per outermost CSG evaluation: a CSG object whose primitives can
+    produce more is refused at rt_scene_create (never a silent overflow during a render); csg_depth must be the real
+    nesting; a CSG object below a group operand is unsupported."""
+    from conftest import N, S, translation
+    # a group of 9 spheres as an operand: 18 possible roots + 2 of the cube
+    sb2 = S.SceneBuilder()
+    many2 = sb2.group([sb2.primitive(N.SPHERE, None, translation(0.2 * k, 0., 0.)) for k in range(9)])
+    sb2.add_object(sb2.csg(N.CSG_UNION, many2, sb2.primitive(N.CUBE)))
+    rc, msg = _create(sb2.flatten(build_bvh=False).desc)
+    assert rc == -2 and "RT_CSG_LIST_MAX" in msg
+    # wrong csg_depth
+    sb3 = S.SceneBuilder()
+    sb3.add_object(sb3.csg(N.CSG_DIFFERENCE, sb3.csg(N.CSG_UNION, sb3.primitive(N.SPHERE), sb3.primitive(N.CUBE)), sb3.primitive(N.SPHERE)))
+    flat3 = sb3.flatten(build_bvh=False)
+    assert sorted(flat3.array("csg_depth")) == [0, 1]
+    rc, msg = _create(_patched(flat3, csg_depth=[0, 0])[0])
+    assert rc == -1 and "csg_depth" in msg
+    # a CSG object inside a group that is a CSG operand
+    sb4 = S.SceneBuilder()
+    g = sb4.group([sb4.csg(N.CSG_UNION, sb4.primitive(N.SPHERE), sb4.primitive(N.CUBE))])
+    sb4.add_object(sb4.csg(N.CSG_INTERSECTION, g, sb4.primitive(N.SPHERE)))
+    rc, msg = _create(sb4.flatten(build_bvh=False).desc)
+    assert rc == -2 and "CSG object inside a group" in msg

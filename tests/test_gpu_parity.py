@@ -151,13 +151,92 @@ def test_invalid_arguments_fail_loudly():
     assert b"required" in L.rt_last_error() or len(L.rt_last_error()) > 0
 
 
-def test_group_as_csg_operand_is_rejected():
+def _csg_with_group_operands():
+    """A CSG object whose operands are GROUPS (csg.rs:113-115 + group.rs:171-201 + object.rs:98-104): left = a group of two
+    overlapping spheres and a nested group holding a cube, right = a group of one cylinder; plus a floor and a light."""
     sb = S.SceneBuilder()
-    g = sb.group([sb.primitive(N.SPHERE)])
-    sb.add_object(sb.csg(N.CSG_UNION, g, sb.primitive(N.CUBE)))
-    with pytest.raises(R.RtError) as e:
-        R.DeviceScene(sb.flatten())
-    assert e.value.code == -2
+    red = S.Material(S.Pattern(N.P_CONST, (1., 0.2, 0.2)), reflectivity=0.2)
+    glass = S.Material.glass()
+    inner = sb.group([sb.primitive(N.CUBE, red, S.matrix_from_transformations([S.Transformation.scaling(0.4, 0.4, 0.4),
+                                                                                   S.Transformation.translation(0.9, 0.2, 0.)]))])
+    left = sb.group([sb.primitive(N.SPHERE, red), sb.primitive(N.SPHERE, glass, translation(0.7, 0., 0.)), inner])
+    right = sb.group([sb.primitive(N.CYLINDER, S.Material(S.Pattern(N.P_CONST, (0.2, 0.2, 1.))),
+                                   S.matrix_from_transformations([S.Transformation.scaling(0.5, 1., 0.5)]), y_min=-2., y_max=2., closed=True)])
+    sb.add_object(sb.csg(N.CSG_DIFFERENCE, left, right))
+    sb.add_object(sb.primitive(N.PLANE, S.Material(S.Pattern(N.P_CHECKERS, (1., 1., 1.), (0.3, 0.3, 0.3))), translation(0., -1.2, 0.)))
+    sb.add_light((-4., 6., -6.), (1., 1., 1.))
+    sb.add_light((5., 3., -2.), (0.4, 0.4, 0.4))
+    return sb
+
+
+@pytest.mark.parametrize("build_bvh", [False, True])
+def test_group_as_csg_operand(build_bvh):
+    """Groups as CSG operands are walked like ObjectGroup::intersect_iter into the CSG's temporary collector, whose closest
+    positive t prunes the walk (group.rs:182 inside csg.rs:113-115): pixels and random rays equal the oracle's, which
+    restates exactly that."""
+    flat = _csg_with_group_operands().flatten(build_bvh=build_bvh)
+    assert flat.desc.n_csgs == 1 and (int(flat.array("csg_left")[0]) >> 30) == N.RT_REF_NODE
+    cam = S.make_camera(120, 96, 1.0, S.view_transformation((1.5, 1.5, -5.), (0.3, 0., 0.), (0., 1., 0.)))
+    check_against_oracle(flat, cam, S.make_options(2, 5, True))
+    rng = np.random.default_rng(5)
+    n = 2048
+    origins = rng.uniform(-3, 3, (n, 3))
+    dirs = rng.normal(size=(n, 3))
+    dirs /= np.linalg.norm(dirs, axis=1, keepdims=True)
+    opt = S.make_options(1, 4, True)
+    sc = R.DeviceScene(flat)
+    got = sc.trace_rays(opt, origins, dirs)
+    want = np.stack([O.color_at(flat, opt, o, d) for o, d in zip(origins, dirs)])
+    assert float(np.abs(got - want).max()) < F64_TOL
+    ref = sc.trace_rays(_ref_order(opt), origins, dirs)
+    assert float(np.abs(ref - want).max()) < F64_TOL
+
+
+def test_csg_unit_test_rays_on_device():
+    """The rays of the reference's CSG unit tests (csg.rs:278-310: a miss; union of two spheres hit at t = 4 and 6.5), and
+    of cube-minus-sphere, through rt_trace_rays: colours equal the oracle's."""
+    opt = S.make_options(1, 4, True)
+    cases = []
+    for op, tr in ((N.CSG_UNION, None), (N.CSG_UNION, translation(0., 0., 0.5)), (N.CSG_INTERSECTION, translation(0., 0., 0.5)),
+                   (N.CSG_DIFFERENCE, translation(0., 0., 0.5))):
+        sb = S.SceneBuilder()
+        sb.add_object(sb.csg(op, sb.primitive(N.SPHERE), sb.primitive(N.SPHERE if tr is not None else N.CUBE, None, tr)))
+        sb.add_light((-10., 10., -10.), (1., 1., 1.))
+        cases.append(sb.flatten(build_bvh=False))
+    rays = [((0., 2., -5.), (0., 1., 0.)), ((0., 0., -5.), (0., 0., 1.)), ((0.3, 0.2, -5.), (0., 0., 1.)), ((0., 0., 5.), (0., 0., -1.))]
+    for flat in cases:
+        got = R.DeviceScene(flat).trace_rays(opt, [r[0] for r in rays], [r[1] for r in rays])
+        want = np.stack([O.color_at(flat, opt, o, d) for o, d in rays])
+        assert np.array_equal(got[0], [0., 0., 0.])
+        assert float(np.abs(got - want).max()) < F64_TOL
+
+
+def test_rt_render_with_null_stats_is_the_hook_call():
+    """ffi/hook.rs calls rt_render(scene, camera, options, out, NULL) (renderer.rs:68-98 replaced): the production kernels,
+    no statistics launch — same pixels as the call with statistics, equal to the oracle's, and a second frame of the same
+    scene (an animation through the hook: a new rt_scene per call) as well."""
+    for name, kw in (("chapters/refractions", dict(width=160, height=120, depth=5, supersampling_level=2)),
+                     ("general/dragons", dict(width=200, height=160, depth=5, supersampling_level=2))):
+        rs = Y.load_scene(scene_path("images", name), **kw)
+        flat, cam, opt = rs.builder.flatten(), rs.camera, rs.options()
+        a, st = R.render(flat, cam, opt, want_stats=False)
+        assert st is None
+        b, _ = R.render(flat, cam, opt, want_stats=False)
+        c, st_c = R.render(flat, cam, opt)
+        assert np.array_equal(a, b) and np.array_equal(a, c) and st_c["rays_primary"] == cam.width * cam.height * 4
+        check_against_oracle(flat, cam, opt, gpu=a)
+
+
+def test_dragon_scene_config2_vs_oracle():
+    """BASELINE config 2's stand-in, scenes/dragon.yml (one dragon in a checker room, 2 lights) at 800x800, supersampling
+    2, depth 5 — the file bench.py's dragon_800_ss2_d5 workload renders — against the oracle."""
+    rs = Y.load_scene(os.path.join(os.path.dirname(GOLDEN), "..", "scenes", "dragon.yml"), width=800, height=800, depth=5,
+                      supersampling_level=2)
+    flat, cam, opt = rs.builder.flatten(), rs.camera, rs.options()
+    gpu, _ = R.render(flat, cam, opt, want_stats=False)
+    cpu, _ = O.render(flat, cam, opt, n_threads=16)
+    assert float(np.abs(gpu - cpu).max()) < F64_TOL
+    assert np.array_equal(O.quantize(gpu), O.quantize(cpu))
 
 
 # ---- the reference's unit-test rays through the device path (rt_trace_rays) ---------------------------
@@ -339,6 +418,13 @@ def test_full_size_4k_production_equals_reference_order():
     assert st["overflow_pixels"] == 0 and st["rays_primary"] == 3840 * 2160 * 16
     assert float((a - b).abs().max().item()) < 1e-12
     assert float((a > 0).double().mean().item()) > 0.05
+    # the kernels that bench.py times are the ones WITHOUT counters: the same frame through them, twice (the second
+    # frame is laid out by what the first reported: one batch instead of two)
+    for _ in range(2):
+        a.zero_()
+        scene.render_device(cam, opt, a.data_ptr())
+        torch.cuda.synchronize()
+        assert torch.equal(a, b)
 
 
 # ---- the streamed pipeline against the single-kernel core, batches, overflow fallback -----------------------------
