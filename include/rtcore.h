@@ -263,6 +263,22 @@ int rt_assemble_tiles_device(uint32_t width, uint32_t height, uint32_t n_parts, 
 int rt_render_device(const rt_scene* scene, const rt_camera* camera, const rt_options* options,
                      double* d_out_rgb, void* hip_stream, rt_stats* stats /* nullable */);
 
+/* rt_render_device for callers that cannot allocate: code under HIP graph capture, tight serving loops, harnesses that
+ * forbid hipMalloc.  It has no counterpart in the reference.  Same pixels as rt_render_device (streamed production
+ * pipeline; options->reference_order and options->pipeline must be 0), but the ray queues, hit and node records, shadow
+ * values and counters of the pipeline live in ONE static device array of RT_NOALLOC_SCRATCH_BYTES per GPU instead of a
+ * workspace the library allocates, and the call makes no hipMalloc / hipFree / hipHostMalloc / hipEventCreate, nor
+ * anything else that allocates: only kernel launches, hipMemsetAsync and one hipEventRecord on `hip_stream`.  A frame larger
+ * than the array is rendered in batches of 8x8 tiles; more than RT_NOALLOC_MAX_BATCHES batches (or a scene with so many
+ * lights that one tile's batch does not fit) is refused with RT_ERR_UNSUPPORTED and a message giving the limit in
+ * samples (about 90 000 samples per batch for a 2-light scene: 1200x1200 at supersampling 2 fits).  Every call on a GPU
+ * uses that GPU's array: calls that overlap on one GPU (other streams, other threads, other scenes) race; the array keeps
+ * the previous call's contents, everything that has to start at zero is cleared by the call itself. */
+#define RT_NOALLOC_SCRATCH_BYTES (64u * 1024u * 1024u)
+#define RT_NOALLOC_MAX_BATCHES 64u
+int rt_render_device_noalloc(const rt_scene* scene, const rt_camera* camera, const rt_options* options,
+                             double* d_out_rgb, void* hip_stream);
+
 /* `Color::as_scaled_values` (src/math/color.rs:55-66) + `Image::as_u8_rgb` (image.rs:84-89) on device:
  * n_pixels*3 f64 -> n_pixels*3 u8 (round-half-away(clamp(v,0,1)*255), NaN -> 0). */
 int rt_quantize_device(const double* d_rgb, uint64_t n_values, uint8_t* d_out_u8, void* hip_stream);

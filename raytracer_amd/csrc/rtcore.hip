@@ -225,6 +225,29 @@ namespace {
 
 thread_local std::string g_err;
 
+// rt_render_device_noalloc's workspace (include/rtcore.h): ONE array per GPU for the life of the process, shared by every
+// call on that GPU.  In host code `scratch` is only a handle for hipGetSymbolAddress: the address kernels and
+// hipMemsetAsync are given is the per-device one kept in g_scratch_ptr (resolved by rt_scene_create, with the scene's
+// device current).
+static __device__ __align__(256) unsigned char scratch[RT_NOALLOC_SCRATCH_BYTES];
+#define RT_MAX_DEVICES 64
+std::mutex g_scratch_mu;
+void* g_scratch_ptr[RT_MAX_DEVICES] = {};
+bool g_scratch_tried[RT_MAX_DEVICES] = {};
+
+// The address of `scratch` on the CURRENT device `device` (NULL when it cannot be had: the entry point then says so).
+void* scratch_on_device(int device) {
+  if (device < 0 || device >= RT_MAX_DEVICES) return nullptr;
+  std::lock_guard<std::mutex> lock(g_scratch_mu);
+  if (!g_scratch_tried[device]) {
+    g_scratch_tried[device] = true;
+    void* ptr = nullptr;
+    if (hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch)) == hipSuccess) g_scratch_ptr[device] = ptr;
+    else (void)hipGetLastError();
+  }
+  return g_scratch_ptr[device];
+}
+
 int fail(int code, const std::string& msg) {
   g_err = msg;
   return code;
@@ -423,6 +446,7 @@ struct rt_scene {
   struct StageBuffer* stage = nullptr;             // while rt_scene_create runs: the arena's contents on the host
   std::vector<std::pair<size_t, void*>> fixups;    // (offset in the arena, address of the device pointer to set)
   int device = 0;
+  void* noalloc_scratch = nullptr;          // this device's copy of the `scratch` array (rt_render_device_noalloc)
   mutable hipEvent_t done_event = nullptr;  // recorded after every render: what the destructor waits for
   mutable bool rendered = false;
   unsigned long long* d_stats = nullptr;  // RT_N_COUNTERS counters
@@ -1457,6 +1481,7 @@ int rt_scene_create(const rt_scene_desc* d, rt_scene** out) {
   t_stage.size = 0;
   sc->stage = &t_stage;
   (void)hipGetDevice(&sc->device);
+  sc->noalloc_scratch = scratch_on_device(sc->device);
   sc->stack_need = need;
 #define UP(vec, field)                                 \
   do {                                                 \
@@ -1575,6 +1600,51 @@ int rt_render_tiles_device(const rt_scene* scene, const rt_camera* camera, const
 int rt_render_device(const rt_scene* scene, const rt_camera* camera, const rt_options* options, double* d_out_rgb, void* hip_stream,
                      rt_stats* stats) {
   return launch_render(scene, camera, options, 0, 1, 0, d_out_rgb, (hipStream_t)hip_stream, stats);
+}
+
+int rt_render_device_noalloc(const rt_scene* scene, const rt_camera* camera, const rt_options* options, double* d_out_rgb, void* hip_stream) {
+  int rc = check_render_args(scene, camera, options);
+  if (rc) return rc;
+  if (!d_out_rgb) return fail(RT_ERR_INVALID_ARGUMENT, "output buffer is NULL");
+  if (options->reference_order || options->pipeline != RT_PIPELINE_STREAM)
+    return fail(RT_ERR_INVALID_ARGUMENT, "rt_render_device_noalloc renders with the streamed production pipeline only");
+  char* base = (char*)scene->noalloc_scratch;
+  if (!base) return fail(RT_ERR_DEVICE, "the static scratch array could not be located on this device (hipGetSymbolAddress)");
+  hipStream_t st = (hipStream_t)hip_stream;
+  uint32_t tiles_x;
+  const uint32_t n_tiles = tiles_total(camera->width, camera->height, &tiles_x);
+  DevOptions dopt = dev_options(options);
+  const uint32_t per_tile = 64u * dopt.n_offsets * dopt.n_offsets;
+  const uint32_t ratio = scene->nodes_per_sample;
+  // the largest whole number of tiles whose batch fits the array
+  stream::Ws w{};
+  uint64_t lo = 0, hi = std::max<uint64_t>(1, std::min<uint64_t>(n_tiles, RT_NOALLOC_SCRATCH_BYTES / per_tile));
+  while (lo < hi) {
+    uint64_t mid = (lo + hi + 1) / 2;
+    if (carve_workspace(nullptr, nullptr, mid * per_tile, ratio, scene->n_lights) <= RT_NOALLOC_SCRATCH_BYTES) lo = mid;
+    else hi = mid - 1;
+  }
+  if (lo == 0)
+    return fail(RT_ERR_UNSUPPORTED, "rt_render_device_noalloc: one 8x8 tile of this scene and these options does not fit the " +
+                                        std::to_string(RT_NOALLOC_SCRATCH_BYTES >> 20) + " MiB scratch array");
+  const uint64_t n_batches = (n_tiles + lo - 1) / lo;
+  if (n_batches > RT_NOALLOC_MAX_BATCHES)
+    return fail(RT_ERR_UNSUPPORTED, "rt_render_device_noalloc: the frame has " + std::to_string((uint64_t)n_tiles * per_tile) +
+                                        " samples; at most " + std::to_string(lo * per_tile * RT_NOALLOC_MAX_BATCHES) +
+                                        " (RT_NOALLOC_MAX_BATCHES batches of the scratch array) are rendered for this scene and these options");
+  const uint32_t batch_samples = (uint32_t)(lo * per_tile);
+  carve_workspace(&w, base, batch_samples, ratio, scene->n_lights);
+  HIP_TRY(hipMemsetAsync(scene->d_overflow, 0, sizeof(uint32_t), st));
+  rc = stream_render_with<false>(scene, w, batch_samples, camera, dopt, 0, 1, tiles_x, n_tiles, 0, d_out_rgb, st);
+  if (rc) {
+    (void)hipStreamSynchronize(st);
+    return rc;
+  }
+  // (the fallback kernel's frame summary is for the allocating entry points' layout heuristics: not carried over)
+  HIP_TRY(hipMemsetAsync(scene->d_summary, 0, 3 * sizeof(uint32_t), st));
+  scene->rendered = true;
+  HIP_TRY(hipEventRecord(scene->done_event, st));
+  return RT_OK;
 }
 
 int rt_assemble_tiles_device(uint32_t width, uint32_t height, uint32_t n_parts, uint32_t part_stride_tiles,

@@ -78,6 +78,10 @@ class DeviceScene:
                                         C.byref(st) if st is not None else None))
         return st.as_dict() if st is not None else None
 
+    def render_device_noalloc(self, camera: N.rt_camera, options: N.rt_options, d_out_ptr: int, stream: int = 0):
+        """rt_render_device_noalloc: the same frame out of the library's static scratch array (no allocation in the call)."""
+        _check(self._L.rt_render_device_noalloc(self._h, C.byref(camera), C.byref(options), C.c_void_p(d_out_ptr), C.c_void_p(stream)))
+
 
 def tile_count(width: int, height: int, part: int, n_parts: int) -> int:
     return N.core_lib().rt_tile_count(width, height, part, n_parts)

@@ -1,0 +1,52 @@
+"""rt_render_device_noalloc (include/rtcore.h): the variant of rt_render_device for callers that cannot allocate.  Through
+the C-ABI, against rt_render_device's own output, bit for bit, on two calls in a row — the second with a smaller input,
+so that whatever the first left in the static scratch array is under the second's feet."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, N, S
+from raytracer_amd import renderer as R
+from raytracer_amd import scene_yaml as Y
+
+pytestmark = pytest.mark.gpu
+
+
+def _scene(name, **kw):
+    rs = Y.load_scene(os.path.join(GOLDEN, "scenes", "images", name + ".yml"), **kw)
+    return R.DeviceScene(rs.builder.flatten()), rs.camera, rs.options()
+
+
+def test_noalloc_entry_point_equals_render_device():
+    import torch
+    L = N.core_lib()
+    big = _scene("chapters/refractions", width=400, height=304, depth=5, supersampling_level=2)   # several batches of the array
+    small = _scene("general/cover", width=96, height=72, depth=4, supersampling_level=1)          # one partial batch
+    outs = {}
+    for key, (sc, cam, opt) in (("big", big), ("small", small)):
+        want = torch.empty((cam.height, cam.width, 3), dtype=torch.float64, device="cuda")
+        sc.render_device(cam, opt, want.data_ptr())
+        torch.cuda.synchronize()
+        outs[key] = want
+    stream = torch.cuda.current_stream().cuda_stream
+    for rnd in range(2):
+        for key, (sc, cam, opt) in (("big", big), ("small", small)):  # two calls in a row, the second with a smaller input
+            got = torch.full((cam.height, cam.width, 3), float("nan"), dtype=torch.float64, device="cuda")
+            torch.cuda.synchronize()
+            free0 = torch.cuda.mem_get_info()[0]
+            sc.render_device_noalloc(cam, opt, got.data_ptr(), stream)
+            torch.cuda.synchronize()
+            assert torch.cuda.mem_get_info()[0] == free0, "the call changed the amount of free device memory"
+            assert torch.equal(got, outs[key]), (rnd, key)
+    # beyond the maximum: a clear error, nothing rendered
+    sc, cam, opt = small
+    huge = S.make_camera(8192, 8192, 1.0)
+    opt5 = S.make_options(5, 4, True)
+    dummy = torch.zeros(16, dtype=torch.float64, device="cuda")
+    rc = L.rt_render_device_noalloc(sc.handle, C.byref(huge), C.byref(opt5), C.c_void_p(dummy.data_ptr()), None)
+    assert rc == -2 and b"RT_NOALLOC_MAX_BATCHES" in L.rt_last_error()
+    ref = S.make_options(1, 4, True)
+    ref.reference_order = 1
+    assert L.rt_render_device_noalloc(sc.handle, C.byref(cam), C.byref(ref), C.c_void_p(dummy.data_ptr()), None) == -1

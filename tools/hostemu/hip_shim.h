@@ -67,6 +67,9 @@ static inline hipError_t hipGetLastError() { return hipSuccess; }
 static inline hipError_t hipGetDeviceCount(int* n) { *n = 1; return hipSuccess; }
 static inline hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
 static inline hipError_t hipMalloc(void** p, size_t n) { *p = std::malloc(n); return hipSuccess; }
+#define __align__(n) alignas(n)
+#define HIP_SYMBOL(x) (&(x))
+template <class T> static inline hipError_t hipGetSymbolAddress(void** p, T* symbol) { *p = (void*)symbol; return hipSuccess; }
 static inline hipError_t hipFree(void* p) { std::free(p); return hipSuccess; }
 enum { hipHostMallocPortable = 1, hipStreamNonBlocking = 1, hipEventDisableTiming = 2 };
 static inline hipError_t hipHostMalloc(void** p, size_t n, unsigned = 0) { *p = std::malloc(n); return hipSuccess; }
