@@ -8,7 +8,7 @@ metric = Mrays/s over unique rays (primary + shadow + reflect + refract; each re
 per hit), whole job.  N > 1: the frame's 8x8 tiles are dealt cyclically to the ranks (strong scaling: the frame is
 fixed), one gather to rank 0 + an un-interleave kernel inside the timed region.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W          (N > 1 without a launcher: starts its own N ranks)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 """
 from __future__ import annotations
@@ -16,14 +16,17 @@ from __future__ import annotations
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
-FP64_PEAK_TFLOPS = 78.6  # MI355X_MICROARCH.md: vector FP64 peak (no matrix cores on this path)
+HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+L2_PEAK_GBS = 34500.0     # MI355X_MICROARCH.md: aggregate L2 bandwidth (8 XCDs)
+FP64_PEAK_TFLOPS = 78.6   # MI355X_MICROARCH.md: vector FP64 peak (no matrix cores on this path)
 
 WORKLOADS = {
     # name: (scene file, width, height, supersampling level, depth)
@@ -34,15 +37,31 @@ WORKLOADS = {
     "readme_800_ss2_d5": ("scenes/readme.yml", 800, 800, 2, 5),
 }
 
+# SURVEY.md §8d's per-unit constants (layout-independent on purpose): bytes and f64 operations of the reference's own
+# arithmetic per box test / triangle test / analytic-primitive test.
+BYTES = {"box": 52, "tri": 72, "prim": 113}
+FLOPS = {"box": 22, "tri": 45, "prim": 40}
+
 
 def algorithmic_bytes(st: dict, n_pixels: int) -> int:
-    """SURVEY.md §8d constants: node visit 48 B box + 4 B ref; triangle test 72 B; analytic primitive test 96 B
-    inverse + 17 B params; hit shading bytes counted per hit by the kernel; output 24 B/pixel."""
-    return 52 * st["node_visits"] + 72 * st["tri_tests"] + 113 * st["prim_tests"] + st["hit_bytes"] + 24 * n_pixels
+    """node visit 48 B box + 4 B ref; triangle test 72 B; analytic primitive test 96 B inverse + 17 B params; hit shading
+    bytes counted per hit by the kernel; output 24 B/pixel."""
+    return (BYTES["box"] * st["node_visits"] + BYTES["tri"] * st["tri_tests"] + BYTES["prim"] * st["prim_tests"] + st["hit_bytes"] +
+            24 * n_pixels)
 
 
 def unique_rays(st: dict) -> int:
     return st["rays_primary"] + st["rays_shadow"] + st["rays_reflect"] + st["rays_refract"]
+
+
+def cpu_model() -> str:
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
 
 
 def cpu_baseline(flat, camera, options, budget_s: float = 15.0) -> dict:
@@ -78,9 +97,22 @@ def cpu_baseline(flat, camera, options, budget_s: float = 15.0) -> dict:
         if t_spent >= budget_s:
             break
     return {"value": uniq / t_spent / 1e6, "unit": "Mrays/s", "cores": threads, "kind": "port",
+            "cpu_model": cpu_model(), "host_cores": os.cpu_count(),
             "sample": f"{rows} of {h} rows (8-row strips spread over the frame), {uniq} unique rays "
-                      f"({equiv} reference-equivalent rays with per-light re-tracing) in {t_spent:.1f} s",
+                      f"({equiv} reference-equivalent rays with per-light re-tracing) in {t_spent:.1f} s on {threads} threads",
             "reference_equivalent_mrays_s": equiv / t_spent / 1e6}
+
+
+def self_launch(args) -> int:
+    """`python bench.py --gpus N` without a launcher: start the N ranks (one process per GPU, torch.distributed.run) as a
+    CHILD process — this process has made no GPU call and makes none — and pass their output through."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd).returncode
 
 
 def main():
@@ -90,8 +122,13 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="dragons_4k_ss4_d5", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-one-shot", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=15.0)
     args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world == 1 and args.gpus > 1:
+        sys.exit(self_launch(args))
 
     import torch
     import torch.distributed as dist
@@ -101,11 +138,7 @@ def main():
     from raytracer_amd import scene_yaml as Y
 
     rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
     torch.cuda.set_device(local_rank)
     if world > 1:
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
@@ -127,7 +160,9 @@ def main():
     else:
         local = torch.zeros(n_max * 64 * 3, dtype=torch.float64, device="cuda")
         out = torch.empty((h, w, 3), dtype=torch.float64, device="cuda") if rank == 0 else None
-        bufs = [torch.empty_like(local) for _ in range(world)] if rank == 0 else None
+        # ONE gather buffer, pre-sliced: the gather delivers each part where the un-interleave kernel reads it
+        allparts = torch.empty((world, n_max * 64 * 3), dtype=torch.float64, device="cuda") if rank == 0 else None
+        bufs = [allparts[p] for p in range(world)] if rank == 0 else None
 
     import ctypes as C
 
@@ -156,8 +191,7 @@ def main():
         if world > 1:
             dist.gather(local, gather_list=bufs, dst=0)
             if rank == 0:
-                g = torch.stack(bufs, 0)
-                R.assemble_tiles(w, h, world, n_max, g.data_ptr(), out.data_ptr(), stream)
+                R.assemble_tiles(w, h, world, n_max, allparts.data_ptr(), out.data_ptr(), stream)
 
     def barrier():
         if world > 1:
@@ -167,13 +201,12 @@ def main():
     # Untimed statistics launches (same rays, same pixels):
     #  * reference-order mode (rt_options.reference_order = 1): the BVH is visited exactly as ObjectGroup::intersect_iter
     #    does: its image is the full-size cross-check of the production pipeline, its counts the reference's own work.
-    #  * production mode with counters: the units each production kernel processes -> algorithmic bytes per launch.
+    #  * production mode with counters: the units each production kernel processes -> algorithmic work per launch.
     target = out if world == 1 else local
     st_ref = launch(clone_options(opt, reference_order=1), True)
     ref_img = target.clone()
     st = launch(opt, True)
-    xdiff = float((target - ref_img).abs().max().item())
-    del ref_img
+    xdiff_counted = float((target - ref_img).abs().max().item())
     for _ in range(args.warmup):
         step()
     barrier()
@@ -182,6 +215,20 @@ def main():
         step(record=True)
     barrier()
     elapsed = time.perf_counter() - t0
+    # what the timed steps left in the output: the image of the kernels that were TIMED (no counters), against the
+    # reference-order image
+    xdiff_timed = float((target - ref_img).abs().max().item())
+    del ref_img
+
+    one_shot_ms = None
+    if world == 1 and not args.no_one_shot:
+        # the drop-in entry (rt_render: host buffers in, host pixels out; PCIe, scene upload and layout included), as the
+        # reference-side hook calls it (stats = NULL); the second call is what an animation's frames cost
+        for _ in range(2):
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            R.render(flat, cam, opt, want_stats=False)
+            one_shot_ms = (time.perf_counter() - t1) * 1e3
 
     def mean(key):
         return sum(p[key] for p in per_step) / len(per_step)
@@ -191,8 +238,8 @@ def main():
             "shadow_node_visits", "shadow_tri_tests", "shadow_prim_tests", "rays_shadow_culled"]
     tkeys = ["ms_kernel", "ms_trace_closest", "ms_retrace", "ms_shade", "ms_trace_shadow", "ms_combine", "ms_other",
              "launches_trace_closest", "launches_trace_shadow"]
-    extra = [elapsed, float(algorithmic_bytes(st_ref, n_pix_rank)), float(st["lane_steps"]), float(st["wave_steps"]), xdiff,
-             float(st["fallback_flags"])]
+    extra = [elapsed, float(algorithmic_bytes(st_ref, n_pix_rank)), float(st["lane_steps"]), float(st["wave_steps"]),
+             max(xdiff_counted, xdiff_timed), float(st["fallback_flags"])]
     vec = torch.tensor([float(st[k]) for k in keys] + [mean(k) for k in tkeys] + extra, dtype=torch.float64, device="cuda")
     if world > 1:
         allv = [torch.empty_like(vec) for _ in range(world)]
@@ -208,32 +255,34 @@ def main():
         t_max = float(allv[:, ex].max())
         rays = unique_rays(tot)
         value = rays * args.steps / t_max / 1e6
-        # Roofline of the dominant kernel on rank 0: the trace kernel class with the most GPU time per step.
-        shadow_bytes = 52 * r0["shadow_node_visits"] + 72 * r0["shadow_tri_tests"] + 113 * r0["shadow_prim_tests"]
-        closest_bytes = (52 * (r0["node_visits"] - r0["shadow_node_visits"]) + 72 * (r0["tri_tests"] - r0["shadow_tri_tests"]) +
-                         113 * (r0["prim_tests"] - r0["shadow_prim_tests"]))
+        # The dominant kernel on rank 0: the trace kernel class with the most GPU time per step, and its units.
+        units = {"shadow": {"box": r0["shadow_node_visits"], "tri": r0["shadow_tri_tests"], "prim": r0["shadow_prim_tests"]}}
+        units["closest"] = {"box": r0["node_visits"] - r0["shadow_node_visits"], "tri": r0["tri_tests"] - r0["shadow_tri_tests"],
+                            "prim": r0["prim_tests"] - r0["shadow_prim_tests"]}
+        csg = "true" if flat.desc.n_csgs else "false"  # (the counter-free trace kernels come with and without the CSG code)
         if tm["ms_trace_shadow"] >= tm["ms_trace_closest"]:
-            kname, k_ms, k_launches, k_bytes = "stream::trace_shadow_kernel<false>", tm["ms_trace_shadow"], tm["launches_trace_shadow"], shadow_bytes
+            kname, kkey, k_ms, k_launches = f"stream::trace_shadow_kernel<false, {csg}>", "trace_shadow_kernel", tm["ms_trace_shadow"], tm["launches_trace_shadow"]
+            u = units["shadow"]
         else:
-            kname, k_ms, k_launches, k_bytes = "stream::trace_closest_kernel<true, false>", tm["ms_trace_closest"], tm["launches_trace_closest"], closest_bytes
-        # the same kernel against the FP64 vector peak (SURVEY.md §8d flop constants: a box test = 12 mul/sub + 10 min/max/
-        # compare, a triangle test = 45 when it runs to completion (early exits are not separated: an upper bound), an
-        # analytic-primitive test = 18 for the ray transform + ~22 for the shape)
-        if kname.startswith("stream::trace_shadow"):
-            k_flops = 22 * r0["shadow_node_visits"] + 45 * r0["shadow_tri_tests"] + 40 * r0["shadow_prim_tests"]
-        else:
-            k_flops = (22 * (r0["node_visits"] - r0["shadow_node_visits"]) + 45 * (r0["tri_tests"] - r0["shadow_tri_tests"]) +
-                       40 * (r0["prim_tests"] - r0["shadow_prim_tests"]))
+            kname, kkey, k_ms, k_launches = f"stream::trace_closest_kernel<true, false, {csg}>", "trace_closest_kernel", tm["ms_trace_closest"], tm["launches_trace_closest"]
+            u = units["closest"]
         k_launches = max(1.0, k_launches)
-        achieved = k_bytes / max(1e-9, k_ms * 1e-3) / 1e9  # (bytes per launch) / (duration per launch)
-        frame_bytes = float(algorithmic_bytes(r0, n_pix_rank))
-        traffic = None
+        k_s = max(1e-9, k_ms * 1e-3)  # seconds per step spent in that kernel class
+        k_bytes = sum(BYTES[x] * u[x] for x in u)
+        k_flops = sum(FLOPS[x] * u[x] for x in u)
+        # HBM- and L2-side traffic of the same kernel: PMC passes of tools/profile.sh on this workload (profiles/traffic.json)
+        pmc = {}
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tpath):
+        if world == 1 and os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get(args.workload if world == 1 else "", {}).get("hbm_bytes_per_launch")
+                pmc = json.load(open(tpath)).get(args.workload, {}).get(kkey, {})
             except Exception:
-                traffic = None
+                pmc = {}
+        traffic = pmc.get("hbm_bytes_per_launch")
+        l2_bytes = pmc.get("l2_request_bytes_per_launch")
+        ms_launch = k_ms / k_launches
+        frame_bytes = float(algorithmic_bytes(r0, n_pix_rank))
+        fp64 = k_flops / k_s / 1e12
         res = {
             "metric": "Mrays/s (primary+secondary, unique rays, whole job)", "value": value, "unit": "Mrays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": t_max / args.steps * 1e3,
@@ -243,29 +292,37 @@ def main():
                        "rays_per_frame": rays, "primary": tot["rays_primary"], "shadow": tot["rays_shadow"],
                        "reflect": tot["rays_reflect"], "refract": tot["rays_refract"],
                        "shadow_rays_not_traced_light_behind_surface": tot["rays_shadow_culled"],
-                       "pipeline": "single kernel" if opt.pipeline else "streamed", "host_scene_prep_s": round(t_prep, 2)},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": kname, "kernel_ms": k_ms / k_launches, "launches_per_step": k_launches,
-                         "fp64_vector": {"achieved": k_flops / max(1e-9, k_ms * 1e-3) / 1e12, "peak": FP64_PEAK_TFLOPS,
-                                         "unit": "TFLOP/s", "frac": k_flops / max(1e-9, k_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,
-                                         "note": "algorithmic flops of the same launches (22 per box test, 45 per triangle "
-                                                 "test, 40 per analytic-primitive test) / the same durations"},
-                         "algorithmic_bytes_per_launch": k_bytes / k_launches,
+                       "pipeline": "single kernel" if opt.pipeline else "streamed", "host_scene_prep_s": round(t_prep, 2),
+                       "one_shot_ms": one_shot_ms},
+            # The trace kernels walk a ~17 MB scene that lives in L2 / Infinity Cache: HBM is not what bounds them, the
+            # vector units are (VALU issue under SIMD divergence).  So the roofline is priced against the FP64 vector peak
+            # — algorithmic f64 operations of the reference's arithmetic per launch / the launch's duration — which cannot
+            # exceed 1; the memory-side fractions of the same launches stand beside it.
+            "roofline": {"bound": "fp64_vector", "achieved": fp64, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": fp64 / FP64_PEAK_TFLOPS, "traffic": traffic,
+                         "kernel": kname, "kernel_ms": ms_launch, "launches_per_step": k_launches,
+                         "algorithmic_flops_per_launch": k_flops / k_launches,
+                         "hbm": None if traffic is None else {"achieved": traffic / (ms_launch * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                                               "frac": traffic / (ms_launch * 1e-3) / 1e9 / HBM_PEAK_GBS},
+                         "l2": None if l2_bytes is None else {"achieved": l2_bytes / (ms_launch * 1e-3) / 1e9, "peak": L2_PEAK_GBS, "unit": "GB/s",
+                                                               "frac": l2_bytes / (ms_launch * 1e-3) / 1e9 / L2_PEAK_GBS,
+                                                               "note": "TCC_REQ_sum x 128 B per launch"},
+                         "algorithmic_bytes_throughput": {"bytes_per_launch": k_bytes / k_launches, "GB_per_s": k_bytes / k_s / 1e9,
+                                                          "note": "SURVEY.md §8d bytes (52 B per box test, 72 B per triangle test, 113 B per "
+                                                                  "analytic-primitive test) / launch duration: a throughput of cache-resident "
+                                                                  "data, not a fraction of the HBM peak"},
                          "whole_frame": {"ms_gpu": tm["ms_kernel"], "algorithmic_bytes": frame_bytes,
-                                         "achieved": frame_bytes / max(1e-9, tm["ms_kernel"] * 1e-3) / 1e9,
                                          "algorithmic_bytes_reference_order": float(allv[0, ex + 1]),
                                          "ms_by_kernel_class": {k[3:]: tm[k] for k in tkeys if k.startswith("ms_") and k != "ms_kernel"}},
                          "simd_utilisation": float(allv[:, ex + 2].sum() / max(1.0, 64.0 * float(allv[:, ex + 3].sum()))),
-                         "note": "algorithmic bytes = SURVEY.md §8d per-unit constants (52 B per box test, 72 B per triangle "
-                                 "test, 113 B per analytic-primitive test; whole frame: + per-hit shading bytes + 24 B per pixel) x the "
-                                 "units the kernel processes (counted by an identical statistics launch); kernel_ms = mean HIP-event "
-                                 "duration of one launch of that kernel inside the timed steps, on the render's stream.  The scene's "
-                                 "working set (~30 MB) is served from L2 / Infinity Cache, so real HBM traffic (`traffic`, PMC) is "
-                                 "far below the algorithmic figure"},
+                         "note": "algorithmic f64 operations = SURVEY.md §8d constants (22 per box test, 45 per triangle test, 40 per "
+                                 "analytic-primitive test) x the units the kernel processes (counted by an identical statistics launch); "
+                                 "kernel_ms = mean HIP-event duration of one launch of that kernel inside the timed steps, on the render's "
+                                 "stream; traffic / hbm / l2 from the PMC passes of the same workload (profiles/)"},
             "parity": {"max_abs_diff_vs_reference_order_render": float(allv[:, ex + 4].max()),
                        "fallback_flags": int(allv[:, ex + 5].sum()),
-                       "note": "full-size cross-check: production pipeline vs reference-order traversal, f64 pixels"},
+                       "note": "full-size cross-check, f64 pixels: the image left by the TIMED kernels (no counters) and the image of "
+                               "the counting launch, each against the reference-order traversal's"},
         }
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(flat, cam, opt, args.cpu_budget)

@@ -163,7 +163,8 @@ def core_lib() -> C.CDLL:
     L.rt_render_tiles_device.argtypes = [C.c_void_p, cp, op, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, stp]
     L.rt_assemble_tiles_device.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
     L.rt_render_device.argtypes = [C.c_void_p, cp, op, C.c_void_p, C.c_void_p, stp]
-    L.rt_render_device_noalloc.argtypes = [C.c_void_p, cp, op, C.c_void_p, C.c_void_p]
+    if hasattr(L, "rt_render_device_noalloc") or not os.environ.get("RTCORE_LIB"):  # (an older build under A/B may lack it)
+        L.rt_render_device_noalloc.argtypes = [C.c_void_p, cp, op, C.c_void_p, C.c_void_p]
     L.rt_quantize_device.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]
     L.rt_trace_rays.argtypes = [C.c_void_p, op, C.c_uint32, _pd, _pd, _pd]
     if L.rt_abi_version() != RT_ABI_VERSION:

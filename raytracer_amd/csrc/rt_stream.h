@@ -298,7 +298,7 @@ __device__ __forceinline__ void flag_sample(const Ws& w, uint32_t root) {
 #ifndef RT_CLOSEST_WAVES
 #define RT_CLOSEST_WAVES 3  // the closest-hit kernel also carries the container walk and CSG: 168 VGPRs, no spills in its loops (measured best)
 #endif
-template <bool CAMERA, bool STATS>
+template <bool CAMERA, bool STATS, bool CSG>
 __global__ __launch_bounds__(64, RT_CLOSEST_WAVES) void trace_closest_kernel(DevScene s, rt_camera cam, DevOptions opt, Ws w, Batch b,
                                                                           uint32_t level, unsigned long long* stats,
                                                                           uint32_t* overflow_flag) {
@@ -351,7 +351,7 @@ __global__ __launch_bounds__(64, RT_CLOSEST_WAVES) void trace_closest_kernel(Dev
     }
     // ---- traverse; once the queue is dry there is nothing to refill with, so run to completion ----
     uint32_t min_active = __builtin_amdgcn_ballot_w64(exhausted) != 0ull ? 0u : (uint32_t)RT_REFILL_BELOW;
-    fast::trav_run<STATS, fast::MS_CLOSEST_CONTAINERS>(s, T, lds, ovf, cnt, min_active);
+    fast::trav_run<STATS, fast::MS_CLOSEST_CONTAINERS, CSG>(s, T, lds, ovf, cnt, min_active);
     // ---- lanes whose traversal is complete ----
     if (my != RT_NONE && !fast::trav_busy(T)) {
       if (T.mode == fast::M_CLOSEST) {
@@ -668,7 +668,7 @@ __device__ __forceinline__ bool shadow_start(const DevScene& s, fast::Trav& T, d
   return true;
 }
 
-template <bool STATS>
+template <bool STATS, bool CSG>
 __global__ __launch_bounds__(64, RT_TRACE_WAVES) void trace_shadow_kernel(DevScene s, Ws w, unsigned long long* stats,
                                                                          uint32_t* overflow_flag) {
   __shared__ uint2 lds_stack[RT_LDS_STACK * 64];
@@ -715,7 +715,7 @@ __global__ __launch_bounds__(64, RT_TRACE_WAVES) void trace_shadow_kernel(DevSce
       continue;
     }
     uint32_t min_active = __builtin_amdgcn_ballot_w64(exhausted) != 0ull ? 0u : (uint32_t)RT_REFILL_BELOW;
-    fast::trav_run<STATS, fast::MS_SHADOW>(s, T, lds, ovf, cnt, min_active);
+    fast::trav_run<STATS, fast::MS_SHADOW, CSG>(s, T, lds, ovf, cnt, min_active);
     if (my != RT_NONE && !fast::trav_busy(T)) {
       w.shadow[(size_t)light * cap + my] = T.a;
       my = RT_NONE;

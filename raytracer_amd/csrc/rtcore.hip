@@ -454,6 +454,7 @@ struct rt_scene {
   size_t bytes = 0;
   uint32_t stack_need = 0;
   uint32_t n_lights = 0;
+  bool has_csg = false;  // the scene holds CSG objects: the trace kernels built with their evaluation are launched
   int n_cus = 256;
   // workspace of the streamed pipeline: allocated at the first render, kept for the scene's lifetime, grown on demand
   mutable void* ws_base = nullptr;
@@ -1186,8 +1187,13 @@ int run_stream_batch(const rt_scene* sc, const stream::Ws& w, const rt_camera& c
   for (uint32_t level = 0; level <= dopt.max_depth; level++) {
     {
       TimedLaunch t(sc, st, TC_TRACE_CLOSEST);
-      hipLaunchKernelGGL((stream::trace_closest_kernel<CAMERA, STATS>), dim3(closest_grid), dim3(64), 0, st, sc->dev, cam, dopt, w, b,
-                         level, sc->d_stats, sc->d_overflow);
+      // (the kernels without counters come in two builds: with and without the code for CSG objects)
+      if (STATS || sc->has_csg)
+        hipLaunchKernelGGL((stream::trace_closest_kernel<CAMERA, STATS, true>), dim3(closest_grid), dim3(64), 0, st, sc->dev, cam, dopt, w, b,
+                           level, sc->d_stats, sc->d_overflow);
+      else
+        hipLaunchKernelGGL((stream::trace_closest_kernel<CAMERA, false, false>), dim3(closest_grid), dim3(64), 0, st, sc->dev, cam, dopt, w, b,
+                           level, sc->d_stats, sc->d_overflow);
     }
     {
       TimedLaunch t(sc, st, TC_RETRACE);
@@ -1206,7 +1212,10 @@ int run_stream_batch(const rt_scene* sc, const stream::Ws& w, const rt_camera& c
   }
   {
     TimedLaunch t(sc, st, TC_TRACE_SHADOW);
-    hipLaunchKernelGGL((stream::trace_shadow_kernel<STATS>), dim3(trace_grid), dim3(64), 0, st, sc->dev, w, sc->d_stats, sc->d_overflow);
+    if (STATS || sc->has_csg)
+      hipLaunchKernelGGL((stream::trace_shadow_kernel<STATS, true>), dim3(trace_grid), dim3(64), 0, st, sc->dev, w, sc->d_stats, sc->d_overflow);
+    else
+      hipLaunchKernelGGL((stream::trace_shadow_kernel<false, false>), dim3(trace_grid), dim3(64), 0, st, sc->dev, w, sc->d_stats, sc->d_overflow);
   }
   for (uint32_t level = dopt.max_depth + 1; level-- > 0;) {
     TimedLaunch t(sc, st, TC_COMBINE);
@@ -1556,6 +1565,7 @@ int rt_scene_create(const rt_scene_desc* d, rt_scene** out) {
   sc->dev.n_lights = d->n_lights;
   sc->dev.n_prims = d->n_prims;
   sc->n_lights = d->n_lights;
+  sc->has_csg = d->n_csgs > 0;
   sc->shape = ((uint64_t)d->n_prims << 40) ^ ((uint64_t)d->n_nodes << 20) ^ ((uint64_t)d->n_lights << 8) ^ (uint64_t)d->n_materials;
   (void)g_learned.lookup(sc->device, sc->shape, &sc->nodes_per_sample, &sc->ratio_floor);
   if (const char* e = std::getenv("RT_STREAM_NODES_PER_SAMPLE")) {  // where the adaptive ratio starts (tests start it too low)

@@ -81,9 +81,9 @@ def gather_frame(local_tiles, width: int, height: int, rank: int, world: int, di
     if world == 1:
         gathered = local_tiles.unsqueeze(0)
     elif rank == 0:
-        bufs = [torch.empty_like(local_tiles) for _ in range(world)]
-        dist.gather(local_tiles, gather_list=bufs, dst=0)
-        gathered = torch.stack(bufs, 0)
+        # one buffer, pre-sliced: the gather delivers every part where the un-interleave kernel reads it (no second copy)
+        gathered = torch.empty((world, local_tiles.numel()), dtype=local_tiles.dtype, device=local_tiles.device)
+        dist.gather(local_tiles, gather_list=[gathered[p] for p in range(world)], dst=0)
     else:
         dist.gather(local_tiles, gather_list=None, dst=0)
         return None

@@ -326,6 +326,27 @@ def test_tile_partition_equals_whole_image_full_size():
     assert torch.equal(out2, whole)
 
 
+def test_eight_parts_of_the_4k_frame_assemble_to_the_whole():
+    """BASELINE config 5 as the 8-GPU job cuts it (bench.py --gpus 8): the 8 cyclic tile parts of the 3840x2160 ss-4 depth-5
+    frame, rendered one after the other on this GPU into ONE pre-sliced buffer (what the gather fills), un-interleaved on
+    the device, equal the whole-frame render bit for bit."""
+    torch = _torch()
+    rs = Y.load_scene(scene_path("images", "general/dragons"), width=3840, height=2160, depth=5, supersampling_level=4)
+    cam, opt = rs.camera, rs.options()
+    scene = R.DeviceScene(rs.builder.flatten())
+    w, h, n_parts = cam.width, cam.height, 8
+    whole = torch.empty((h, w, 3), dtype=torch.float64, device="cuda")
+    scene.render_device(cam, opt, whole.data_ptr())
+    n_max = D.tile_count(w, h, 0, n_parts)
+    allparts = torch.full((n_parts, n_max * 64 * 3), float("nan"), dtype=torch.float64, device="cuda")
+    for p in range(n_parts):
+        scene.render_tiles(cam, opt, p, n_parts, allparts[p].data_ptr())
+    out = torch.empty_like(whole)
+    R.assemble_tiles(w, h, n_parts, n_max, allparts.data_ptr(), out.data_ptr())
+    torch.cuda.synchronize()
+    assert torch.equal(out, whole)
+
+
 def test_supersample_is_mean_of_offset_renders():
     """color_at_pixel sums the n^2 samples left to right and divides (renderer.rs:57-65): reproduce the ss-2 image from
     four single-sample renders with the offsets applied by hand, in the same order, on the host."""
