@@ -19,6 +19,9 @@ impl Renderer {
             reference_order: 0,
             pipeline: 0,
             timing: 0,
+            n_devices: -1, // every visible GPU: the frame's tiles are dealt to them inside rt_render
+            progress: progressbar.as_ref().map(|_| bump_progress as unsafe extern "C" fn(u64, *mut std::ffi::c_void)),
+            user: progressbar.as_ref().map_or(std::ptr::null_mut(), |pb| pb as *const indicatif::ProgressBar as *mut std::ffi::c_void),
         };
         opt.offsets[..n].copy_from_slice(&self.supersampling_offsets);
         let mut rgb = vec![0f64; image.width() * image.height() * 3];
@@ -31,11 +34,16 @@ impl Renderer {
         for (px, c) in image.pixels_mut().iter_mut().zip(rgb.chunks_exact(3)) {
             *px = Color::new(c[0], c[1], c[2]);
         }
-        if let Some(pb) = progressbar {
-            pb.inc((image.width() * image.height()) as u64); // the bar's unit is pixels shaded (image.rs:73)
-        }
         Ok(())
     }
+}
+
+/// rt_options.progress: called by the library once per finished batch with the pixels finished since the last call — the
+/// unit of the reference's bar (image.rs:73).  ProgressBar is Send + Sync; `user` outlives the rt_render call.
+#[cfg(feature = "mi355x")]
+unsafe extern "C" fn bump_progress(pixels_done: u64, user: *mut std::ffi::c_void) {
+    let pb = &*(user as *const indicatif::ProgressBar);
+    pb.inc(pixels_done);
 }
 
 // render_animation_frame (renderer.rs:68-73):

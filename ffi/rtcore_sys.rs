@@ -1,9 +1,9 @@
-//! `#[repr(C)]` mirror of include/rtcore.h, ABI version 1.  Field order and types follow the header exactly;
+//! `#[repr(C)]` mirror of include/rtcore.h, ABI version 2.  Field order and types follow the header exactly;
 //! tests/test_capi.py checks the same layout for the ctypes mirror against a C compiler.
 #![allow(non_camel_case_types)]
 use std::os::raw::{c_char, c_void};
 
-pub const RT_ABI_VERSION: u32 = 1;
+pub const RT_ABI_VERSION: u32 = 2;
 pub const RT_NONE: u32 = 0xFFFF_FFFF;
 pub const RT_REF_NODE: u32 = 0;
 pub const RT_REF_PRIM: u32 = 1;
@@ -74,6 +74,9 @@ pub struct rt_options {
     pub reference_order: u32, // 1: visit the BVH exactly as ObjectGroup::intersect_iter does (validation; slow)
     pub pipeline: u32,        // 0: streamed kernels (production); 1: single kernel
     pub timing: u32,          // 1 (with stats): per-kernel HIP-event times instead of counters
+    pub n_devices: i32,       // rt_render: 0/1 = the current device, n > 1 = tiles over the first n devices, -1 = all
+    pub progress: Option<unsafe extern "C" fn(pixels_done: u64, user: *mut c_void)>, // pixels finished since the last call
+    pub user: *mut c_void,
 }
 
 extern "C" {

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define RT_ABI_VERSION 1u
+#define RT_ABI_VERSION 2u
 
 /* ---- child references --------------------------------------------------------------------- */
 /* A child reference packs the kind of an `Object` (src/scene/object.rs:26-30) in bits 31..30   */
@@ -157,6 +157,8 @@ typedef struct rt_camera {
 
 /* `Renderer::supersampling_offsets` (renderer.rs:24,40-48), `Integrator::max_recursive_depth` and
  * `Integrator::use_shadow_intensity` (integrator.rs:19-32). */
+typedef void (*rt_progress_fn)(uint64_t pixels_done, void* user);
+
 typedef struct rt_options {
   uint32_t n_offsets;        /* 1..5 */
   double offsets[5];
@@ -172,6 +174,16 @@ typedef struct rt_options {
   uint32_t timing;           /* with stats != NULL and the streamed pipeline: launch the production kernels (no counters; the
                                 counter fields of rt_stats stay 0) with a HIP event before and after every launch, and report
                                 the time per kernel class in rt_stats.ms_* */
+  int32_t n_devices;         /* rt_render only (the reference's host is ONE process with a sequential frame loop,
+                                animation_renderer.rs:109-122, so this is how it reaches more than one GPU): 0 or 1 = the current
+                                HIP device; n > 1 = the frame's 8x8 tiles are dealt cyclically to the first n visible devices
+                                (fewer if fewer are visible), each renders its part from its own copy of the scene, the parts are
+                                copied to the first device, un-interleaved there and downloaded; -1 = all visible devices */
+  rt_progress_fn progress;   /* nullable.  Called with the number of pixels finished since the previous call (the unit of the
+                                reference's progress bar, image.rs:73: `progress_with(pb)` over the pixel iterator), from a thread
+                                of the HIP runtime, once per finished batch of tiles; the calls of one render sum to
+                                width * height.  Must not call back into this library */
+  void* user;                /* passed to `progress` */
 } rt_options;
 #define RT_PIPELINE_STREAM 0u
 #define RT_PIPELINE_SINGLE_KERNEL 1u

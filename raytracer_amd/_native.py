@@ -12,7 +12,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_DIR = os.path.join(_HERE, "lib")
 
-RT_ABI_VERSION = 1
+RT_ABI_VERSION = 2
 RT_NONE = 0xFFFFFFFF
 RT_REF_NODE, RT_REF_PRIM, RT_REF_CSG = 0, 1, 2
 RT_TILE_DIM = 8
@@ -53,9 +53,13 @@ class rt_camera(C.Structure):
                 ("half_width", C.c_double), ("half_height", C.c_double), ("pixel_size", C.c_double)]
 
 
+rt_progress_fn = C.CFUNCTYPE(None, C.c_uint64, C.c_void_p)
+
+
 class rt_options(C.Structure):
     _fields_ = [("n_offsets", C.c_uint32), ("offsets", C.c_double * 5), ("max_depth", C.c_uint32),
-                ("shadow_intensity", C.c_uint32), ("reference_order", C.c_uint32), ("pipeline", C.c_uint32), ("timing", C.c_uint32)]
+                ("shadow_intensity", C.c_uint32), ("reference_order", C.c_uint32), ("pipeline", C.c_uint32), ("timing", C.c_uint32),
+                ("n_devices", C.c_int32), ("progress", rt_progress_fn), ("user", C.c_void_p)]
 
 
 class rt_stats(C.Structure):

@@ -10,6 +10,9 @@
 #include <algorithm>
 #include <chrono>
 #include <mutex>
+#include <thread>
+#include <cstddef>
+#include <new>
 #include <string>
 #include <utility>
 #include <vector>
@@ -984,8 +987,13 @@ DevOptions dev_options(const rt_options* o) {
   return d;
 }
 
+int check_camera_options(const rt_camera* cam, const rt_options* opt);
 int check_render_args(const rt_scene* scene, const rt_camera* cam, const rt_options* opt) {
-  if (!scene || !cam || !opt) return fail(RT_ERR_INVALID_ARGUMENT, "scene, camera and options are required");
+  if (!scene) return fail(RT_ERR_INVALID_ARGUMENT, "scene, camera and options are required");
+  return check_camera_options(cam, opt);
+}
+int check_camera_options(const rt_camera* cam, const rt_options* opt) {
+  if (!cam || !opt) return fail(RT_ERR_INVALID_ARGUMENT, "scene, camera and options are required");
   if (cam->width == 0 || cam->height == 0) return fail(RT_ERR_INVALID_ARGUMENT, "camera width/height must be > 0");
   if (cam->width > (1u << 19) || cam->height > (1u << 19)) return fail(RT_ERR_UNSUPPORTED, "camera width/height above 524288");
   if (opt->n_offsets < 1 || opt->n_offsets > 5) return fail(RT_ERR_INVALID_ARGUMENT, "n_offsets must be 1..5");
@@ -1230,10 +1238,64 @@ int run_stream_batch(const rt_scene* sc, const stream::Ws& w, const rt_camera& c
   return RT_OK;
 }
 
+// rt_options.progress: pixels finished, reported from the stream (a host function behind the batch's last kernel).
+struct Progress {
+  rt_progress_fn fn = nullptr;
+  void* user = nullptr;
+  uint64_t left = 0;  // pixels of this render not reported yet
+};
+struct ProgressCall {
+  rt_progress_fn fn;
+  void* user;
+  uint64_t pixels;
+};
+void progress_trampoline(void* p) {
+  ProgressCall* c = (ProgressCall*)p;
+  c->fn(c->pixels, c->user);
+  delete c;
+}
+// Pixels (inside the image) of the tiles that part `part` of `n_parts` owns.
+uint64_t part_pixels(const rt_camera* cam, uint32_t part, uint32_t n_parts) {
+  uint32_t tiles_x;
+  uint32_t n_tiles = tiles_total(cam->width, cam->height, &tiles_x);
+  if (n_parts == 1) return (uint64_t)cam->width * cam->height;
+  uint64_t n = 0;
+  for (uint32_t t = part; t < n_tiles; t += n_parts) {
+    uint32_t x0 = (t % tiles_x) * RT_TILE_DIM, y0 = (t / tiles_x) * RT_TILE_DIM;
+    n += (uint64_t)std::min(RT_TILE_DIM, cam->width - x0) * std::min(RT_TILE_DIM, cam->height - y0);
+  }
+  return n;
+}
+Progress make_progress(const rt_options* opt, const rt_camera* cam, uint32_t part, uint32_t n_parts) {
+  Progress p;
+  if (opt->progress) {
+    p.fn = opt->progress;
+    p.user = opt->user;
+    p.left = part_pixels(cam, part, n_parts);
+  }
+  return p;
+}
+// Reports up to `pixels` more pixels (all that is left when last) once the work queued on `st` so far has finished.
+int post_progress(Progress* p, hipStream_t st, uint64_t pixels, bool last) {
+  if (!p || !p->fn) return RT_OK;
+  uint64_t n = last ? p->left : std::min(pixels, p->left);
+  if (n == 0) return RT_OK;
+  p->left -= n;
+  ProgressCall* c = new (std::nothrow) ProgressCall{p->fn, p->user, n};
+  if (!c) return fail(RT_ERR_DEVICE, "out of host memory");
+  hipError_t e = hipLaunchHostFunc(st, progress_trampoline, c);
+  if (e != hipSuccess) {
+    delete c;
+    return fail(RT_ERR_DEVICE, std::string("hipLaunchHostFunc failed: ") + hipGetErrorString(e));
+  }
+  return RT_OK;
+}
+
 // The frame's part in batches of at most batch_samples samples through workspace w (laid out for that many).
 template <bool STATS>
 int stream_render_with(const rt_scene* sc, const stream::Ws& w, uint32_t batch_samples, const rt_camera* cam, const DevOptions& dopt,
-                       uint32_t part, uint32_t n_parts, uint32_t tiles_x, uint32_t n_owned, int packed, double* d_out, hipStream_t st) {
+                       uint32_t part, uint32_t n_parts, uint32_t tiles_x, uint32_t n_owned, int packed, double* d_out, hipStream_t st,
+                       Progress* progress = nullptr) {
   const uint32_t n2 = dopt.n_offsets * dopt.n_offsets, per_tile = 64u * n2;
   const uint32_t tiles_per_batch = std::max(1u, batch_samples / per_tile);
   if (tiles_per_batch * per_tile > batch_samples) return fail(RT_ERR_DEVICE, "render workspace smaller than one tile");
@@ -1256,8 +1318,12 @@ int stream_render_with(const rt_scene* sc, const stream::Ws& w, uint32_t batch_s
     int rc = run_stream_batch<true, STATS>(sc, w, *cam, dopt, b, st);
     if (rc) return rc;
     uint32_t grid = std::max(1u, std::min((uint32_t)sc->n_cus * 8u, (b.n_tiles * 64u + 255u) / 256u));
-    TimedLaunch t(sc, st, TC_OTHER);
-    hipLaunchKernelGGL(stream::resolve_kernel, dim3(grid), dim3(256), 0, st, *cam, w, b, d_out);
+    {
+      TimedLaunch t(sc, st, TC_OTHER);
+      hipLaunchKernelGGL(stream::resolve_kernel, dim3(grid), dim3(256), 0, st, *cam, w, b, d_out);
+    }
+    rc = post_progress(progress, st, (uint64_t)b.n_tiles * 64u, tile0 + tiles_per_batch >= n_owned);
+    if (rc) return rc;
   }
   HIP_TRY(hipGetLastError());
   return RT_OK;
@@ -1265,12 +1331,12 @@ int stream_render_with(const rt_scene* sc, const stream::Ws& w, uint32_t batch_s
 
 template <bool STATS>
 int launch_stream_render(const rt_scene* sc, const rt_camera* cam, const DevOptions& dopt, uint32_t part, uint32_t n_parts,
-                         uint32_t tiles_x, uint32_t n_owned, int packed, double* d_out, hipStream_t st) {
+                         uint32_t tiles_x, uint32_t n_owned, int packed, double* d_out, hipStream_t st, Progress* progress) {
   const uint32_t per_tile = 64u * dopt.n_offsets * dopt.n_offsets;
   uint32_t batch_samples = 0;
   int rc = ensure_workspace(sc, (uint64_t)n_owned * per_tile, &batch_samples);
   if (rc) return rc;
-  rc = stream_render_with<STATS>(sc, sc->ws, batch_samples, cam, dopt, part, n_parts, tiles_x, n_owned, packed, d_out, st);
+  rc = stream_render_with<STATS>(sc, sc->ws, batch_samples, cam, dopt, part, n_parts, tiles_x, n_owned, packed, d_out, st, progress);
   if (rc) return rc;
   return post_summary(sc, st);
 }
@@ -1294,6 +1360,7 @@ int launch_render_once(const rt_scene* scene, const rt_camera* cam, const rt_opt
   }
   if (n_owned) {
     DevOptions dopt = dev_options(opt);
+    Progress progress = make_progress(opt, cam, part, n_parts);
     uint32_t grid = (n_owned + 8 * RT_XCD_GROUP - 1) / (8 * RT_XCD_GROUP) * (8 * RT_XCD_GROUP);
 #define RT_LAUNCH_TILES(STATS, REFORDER)                                                                                     \
   hipLaunchKernelGGL((render_tiles_kernel<STATS, REFORDER>), dim3(grid), dim3(64), 0, stream, scene->dev, *cam, dopt, part, \
@@ -1308,8 +1375,9 @@ int launch_render_once(const rt_scene* scene, const rt_camera* cam, const rt_opt
       // rt_options.timing: the production kernels (no counters) with events around every launch
       scene->timing_on = stats && opt->timing;
       scene->timed_class.clear();
-      rc = (stats && !opt->timing) ? launch_stream_render<true>(scene, cam, dopt, part, n_parts, tiles_x, n_owned, packed, d_out, stream)
-                                   : launch_stream_render<false>(scene, cam, dopt, part, n_parts, tiles_x, n_owned, packed, d_out, stream);
+      rc = (stats && !opt->timing)
+               ? launch_stream_render<true>(scene, cam, dopt, part, n_parts, tiles_x, n_owned, packed, d_out, stream, &progress)
+               : launch_stream_render<false>(scene, cam, dopt, part, n_parts, tiles_x, n_owned, packed, d_out, stream, &progress);
       scene->timing_on = false;
       if (rc) {
         (void)hipStreamSynchronize(stream);  // whatever was launched is over before the caller may destroy the scene
@@ -1318,6 +1386,8 @@ int launch_render_once(const rt_scene* scene, const rt_camera* cam, const rt_opt
     }
 #undef RT_LAUNCH_TILES
     HIP_TRY(hipGetLastError());
+    rc = post_progress(&progress, stream, 0, true);  // (whatever the one-kernel modes have not reported: everything)
+    if (rc) return rc;
     scene->rendered = true;
     HIP_TRY(hipEventRecord(scene->done_event, stream));
   }
@@ -1378,12 +1448,142 @@ int launch_render_once(const rt_scene* scene, const rt_camera* cam, const rt_opt
 // not counted, so the frame is rendered again with twice the node records per sample until none is.
 int launch_render(const rt_scene* scene, const rt_camera* cam, const rt_options* opt, uint32_t part, uint32_t n_parts, int packed,
                   double* d_out, hipStream_t stream, rt_stats* stats) {
-  for (;;) {
-    int rc = launch_render_once(scene, cam, opt, part, n_parts, packed, d_out, stream, stats);
+  rt_options again = *opt;
+  again.progress = nullptr;  // (the pixels are reported once, by the first pass)
+  for (int pass = 0;; pass++) {
+    int rc = launch_render_once(scene, cam, pass == 0 ? opt : &again, part, n_parts, packed, d_out, stream, stats);
     if (rc || !stats || stats->fallback_flags == 0 || scene->nodes_per_sample >= RT_STREAM_RATIO_MAX) return rc;
     scene->summary_pending = false;  // the stream is idle here; the same count must not double the ratio again
     scene->nodes_per_sample *= 2;
   }
+}
+
+// rt_options.n_devices -> the devices a one-shot frame is dealt to (the first one gathers).  RT_DEVICE_LIST (development:
+// "0,0,0" runs the multi-device path on one GPU) overrides the list when more than one device is asked for.
+std::vector<int> device_list(const rt_options* opt) {
+  int cur = 0;
+  (void)hipGetDevice(&cur);
+  if (!opt || opt->n_devices == 0 || opt->n_devices == 1) return {cur};
+  if (const char* e = std::getenv("RT_DEVICE_LIST")) {
+    std::vector<int> v;
+    for (const char* p = e; *p;) {
+      char* end = nullptr;
+      long d = std::strtol(p, &end, 10);
+      if (end == p) break;
+      v.push_back((int)d);
+      p = *end == ',' ? end + 1 : end;
+    }
+    if (!v.empty()) return v;
+  }
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || count < 1) return {cur};
+  int n = opt->n_devices < 0 ? count : std::min(opt->n_devices, count);
+  std::vector<int> v;
+  for (int d = 0; d < n; d++) v.push_back(d);
+  return v;
+}
+
+void add_stats(rt_stats* total, const rt_stats& s) {
+  // (rt_stats is counters first, then times: sum the former, take the slowest device's of the latter)
+  const size_t n_counters = offsetof(rt_stats, ms_upload) / sizeof(uint64_t);
+  uint64_t* t = (uint64_t*)total;
+  const uint64_t* a = (const uint64_t*)&s;
+  for (size_t i = 0; i < n_counters; i++) t[i] += a[i];
+  double* td = &total->ms_upload;
+  const double* ad = &s.ms_upload;
+  const size_t n_times = (sizeof(rt_stats) - offsetof(rt_stats, ms_upload)) / sizeof(double);
+  for (size_t i = 0; i < n_times; i++) td[i] = std::max(td[i], ad[i]);
+}
+
+// One frame over several devices from ONE host process (rt_options.n_devices; SURVEY.md §8e for a host that is a single
+// process, animation_renderer.rs:109-122): a host thread per device creates the scene there, renders the device's cyclic
+// share of the 8x8 tiles into a packed buffer and copies it into the gather buffer on the first device; that device
+// un-interleaves (assemble_tiles_kernel) and the image is downloaded from it.
+int render_on_devices(const std::vector<int>& devs, const rt_scene_desc* desc, const rt_camera* cam, const rt_options* opt, double* out_rgb,
+                      rt_stats* stats) {
+  const uint32_t n = (uint32_t)devs.size();
+  int rc = check_camera_options(cam, opt);
+  if (rc) return rc;
+  const uint32_t n_max = rt_tile_count(cam->width, cam->height, 0, n);
+  const size_t part_bytes = (size_t)n_max * 64 * 3 * sizeof(double), image_bytes = (size_t)cam->width * cam->height * 3 * sizeof(double);
+  struct PoolBlock {
+    void* p = nullptr;
+    size_t cap = 0;
+    int device = 0;
+    ~PoolBlock() { g_device_pool.give(p, cap, device); }
+  };
+  int before = 0;
+  (void)hipGetDevice(&before);
+  struct Restore {
+    int d;
+    ~Restore() { (void)hipSetDevice(d); }
+  } restore{before};
+  HIP_TRY(hipSetDevice(devs[0]));
+  PoolBlock gather, image;
+  gather.device = image.device = devs[0];
+  gather.p = g_device_pool.take(part_bytes * n, devs[0], &gather.cap);
+  image.p = g_device_pool.take(image_bytes ? image_bytes : 16, devs[0], &image.cap);
+  if (!gather.p || !image.p) return fail(RT_ERR_DEVICE, "hipMalloc of the gather buffers failed");
+  std::vector<int> rcs(n, RT_OK);
+  std::vector<std::string> errs(n);
+  std::vector<rt_stats> part_stats(n);
+  std::vector<std::thread> workers;
+  for (uint32_t k = 0; k < n; k++)
+    workers.emplace_back([&, k]() {
+      auto run = [&]() -> int {
+        HIP_TRY(hipSetDevice(devs[k]));
+        if (devs[k] != devs[0]) {
+          hipError_t e = hipDeviceEnablePeerAccess(devs[0], 0);  // (already enabled, or not possible: the copy below works either way)
+          (void)e;
+          (void)hipGetLastError();
+        }
+        rt_scene* sc = nullptr;
+        int r = rt_scene_create(desc, &sc);
+        if (r) return r;
+        struct SceneGuard {
+          rt_scene* s;
+          ~SceneGuard() { rt_scene_destroy(s); }
+        } guard{sc};
+        PoolBlock local;
+        local.device = devs[k];
+        local.p = g_device_pool.take(part_bytes ? part_bytes : 16, devs[k], &local.cap);
+        if (!local.p) return fail(RT_ERR_DEVICE, "hipMalloc of a device's tile buffer failed");
+        hipStream_t st = nullptr;
+        HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+        struct StreamGuard {
+          hipStream_t s;
+          ~StreamGuard() { (void)hipStreamDestroy(s); }
+        } sguard{st};
+        std::memset(&part_stats[k], 0, sizeof(rt_stats));
+        r = launch_render(sc, cam, opt, k, n, 1, (double*)local.p, st, stats ? &part_stats[k] : nullptr);
+        if (r == RT_OK || r == RT_ERR_OVERFLOW) {
+          char* dst = (char*)gather.p + (size_t)k * part_bytes;
+          hipError_t e = devs[k] == devs[0] ? hipMemcpyAsync(dst, local.p, part_bytes, hipMemcpyDeviceToDevice, st)
+                                            : hipMemcpyPeerAsync(dst, devs[0], local.p, devs[k], part_bytes, st);
+          if (e != hipSuccess) r = fail(RT_ERR_DEVICE, std::string("copy of a device's tiles to the first device failed: ") + hipGetErrorString(e));
+        }
+        hipError_t e = hipStreamSynchronize(st);
+        if (e != hipSuccess && r == RT_OK) r = fail(RT_ERR_DEVICE, std::string("render on a device failed: ") + hipGetErrorString(e));
+        absorb_summary(sc);
+        return r;
+      };
+      rcs[k] = run();
+      if (rcs[k]) errs[k] = g_err;  // (g_err is per thread)
+    });
+  for (std::thread& t : workers) t.join();
+  for (uint32_t k = 0; k < n; k++)
+    if (rcs[k] && rcs[k] != RT_ERR_OVERFLOW) return fail(rcs[k], "device " + std::to_string(devs[k]) + ": " + errs[k]);
+  HIP_TRY(hipSetDevice(devs[0]));
+  rc = rt_assemble_tiles_device(cam->width, cam->height, n, n_max, (const double*)gather.p, (double*)image.p, nullptr);
+  if (rc) return rc;
+  if (hipMemcpy(out_rgb, image.p, image_bytes, hipMemcpyDeviceToHost) != hipSuccess) return fail(RT_ERR_DEVICE, "download of the image failed");
+  if (stats) {
+    std::memset(stats, 0, sizeof(*stats));
+    for (uint32_t k = 0; k < n; k++) add_stats(stats, part_stats[k]);
+  }
+  for (uint32_t k = 0; k < n; k++)
+    if (rcs[k] == RT_ERR_OVERFLOW) return fail(RT_ERR_OVERFLOW, "device " + std::to_string(devs[k]) + ": " + errs[k]);
+  return RT_OK;
 }
 
 }  // namespace
@@ -1742,6 +1942,11 @@ int rt_trace_rays(const rt_scene* scene, const rt_options* options, uint32_t n, 
 
 int rt_render(const rt_scene_desc* scene_desc, const rt_camera* camera, const rt_options* options, double* out_rgb, rt_stats* stats) {
   if (!out_rgb || !camera) return fail(RT_ERR_INVALID_ARGUMENT, "out_rgb and camera are required");
+  if (!scene_desc || !options) return fail(RT_ERR_INVALID_ARGUMENT, "scene and options are required");
+  {
+    std::vector<int> devs = device_list(options);
+    if (devs.size() > 1) return render_on_devices(devs, scene_desc, camera, options, out_rgb, stats);
+  }
   Event e0, e1, e2, e3;  // (destroyed on every path)
   if (stats) {
     HIP_TRY(e0.create());

@@ -18,7 +18,7 @@ def _ensure_built():
     import __graft_entry__ as g
 
     need = [os.path.join(ROOT, "raytracer_amd", "lib", "librtscene.so"), os.path.join(ROOT, "raytracer_amd", "lib", "librtcore.so"),
-            os.path.join(ROOT, "oracle", "liboracle.so")]
+            os.path.join(ROOT, "oracle", "liboracle.so"), os.path.join(ROOT, "tests", "c_caller", "render_dump")]
     if not all(os.path.exists(p) for p in need):
         g.build()
 

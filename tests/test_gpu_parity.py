@@ -227,6 +227,31 @@ def test_rt_render_with_null_stats_is_the_hook_call():
         check_against_oracle(flat, cam, opt, gpu=a)
 
 
+def test_rt_render_over_several_devices_and_progress(monkeypatch):
+    """rt_options.n_devices: the one-process host (animation_renderer.rs:109-122 is a sequential loop in ONE process) reaches
+    several GPUs through rt_render itself: tiles dealt cyclically, parts copied to the first device, un-interleaved,
+    downloaded.  With one visible device, -1 (all) and 8 degrade to the plain path; RT_DEVICE_LIST = 0,0,0 runs the
+    three-device path on this one GPU.  rt_options.progress reports exactly width * height pixels either way."""
+    rs = Y.load_scene(scene_path("images", "general/cover"), width=203, height=117, depth=5, supersampling_level=2)
+    flat, cam, opt = rs.builder.flatten(), rs.camera, rs.options()
+    want, _ = R.render(flat, cam, opt, want_stats=False)
+    seen = []
+    cb = N.rt_progress_fn(lambda px, user: seen.append(px))
+    for n_devices, fake in ((-1, None), (8, None), (3, "0,0,0"), (2, "0,0")):
+        if fake:
+            monkeypatch.setenv("RT_DEVICE_LIST", fake)
+        o = rs.options()
+        o.n_devices = n_devices
+        o.progress = cb
+        seen.clear()
+        got, st = R.render(flat, cam, o)
+        assert np.array_equal(got, want), (n_devices, fake)
+        assert sum(seen) == cam.width * cam.height and st["rays_primary"] == cam.width * cam.height * 4
+        seen.clear()
+        got, _ = R.render(flat, cam, o, want_stats=False)
+        assert np.array_equal(got, want) and sum(seen) == cam.width * cam.height
+
+
 def test_dragon_scene_config2_vs_oracle():
     """BASELINE config 2's stand-in, scenes/dragon.yml (one dragon in a checker room, 2 lights) at 800x800, supersampling
     2, depth 5 — the file bench.py's dragon_800_ss2_d5 workload renders — against the oracle."""

@@ -16,8 +16,8 @@ from raytracer_amd import scene_yaml as Y
 TEST_SCENES = ["chapters/cubes", "chapters/cylinders", "chapters/groups", "chapters/making-patterns", "chapters/making-scene",
                "chapters/planes", "chapters/reflections", "chapters/refractions", "chapters/shadows", "general/cover",
                "general/dragons", "general/local-transforms"]
-SHOWCASE = [("general/cover", "cover", 1200, 1200), ("chapters/refractions", "refractions", 1200, 1200),
-            ("general/dragons", "dragons", 1200, 800)]
+SHOWCASE = [("general/cover", "cover", 1200, 1200), ("chapters/cubes", "cubes", 1200, 1200),
+            ("chapters/refractions", "refractions", 1200, 1200), ("general/dragons", "dragons", 1200, 800)]
 
 
 def compare(rgb, png_path):

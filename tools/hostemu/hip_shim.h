@@ -68,6 +68,11 @@ static inline hipError_t hipGetDeviceCount(int* n) { *n = 1; return hipSuccess; 
 static inline hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
 static inline hipError_t hipMalloc(void** p, size_t n) { *p = std::malloc(n); return hipSuccess; }
 #define __align__(n) alignas(n)
+typedef void (*hipHostFn_t)(void*);
+static inline hipError_t hipSetDevice(int) { return hipSuccess; }
+static inline hipError_t hipLaunchHostFunc(hipStream_t, hipHostFn_t fn, void* data) { fn(data); return hipSuccess; }
+static inline hipError_t hipDeviceEnablePeerAccess(int, unsigned) { return hipSuccess; }
+static inline hipError_t hipMemcpyPeerAsync(void* d, int, const void* s, int, size_t n, hipStream_t) { std::memcpy(d, s, n); return hipSuccess; }
 #define HIP_SYMBOL(x) (&(x))
 template <class T> static inline hipError_t hipGetSymbolAddress(void** p, T* symbol) { *p = (void*)symbol; return hipSuccess; }
 static inline hipError_t hipFree(void* p) { std::free(p); return hipSuccess; }
