@@ -135,7 +135,7 @@ def main():
 
     from raytracer_amd import distributed as D
     from raytracer_amd import renderer as R
-    from raytracer_amd import scene_yaml as Y
+    from raytracer_amd.harness import scene_yaml as Y
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))

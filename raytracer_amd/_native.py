@@ -103,7 +103,7 @@ _core_lib = None
 
 
 def scene_lib() -> C.CDLL:
-    """librtscene.so — host scene model + flattener (raytracer_amd/host)."""
+    """librtscene.so — host scene model + flattener (raytracer_amd/harness/host)."""
     global _scene_lib
     if _scene_lib is not None:
         return _scene_lib

@@ -23,9 +23,9 @@ from typing import Callable, Dict, List, Optional
 
 import numpy as np
 
-from . import _native as N
-from . import renderer as R
-from .distributed import frames_for_rank
+from .. import _native as N
+from .. import renderer as R
+from ..distributed import frames_for_rank
 
 
 def frame_count(framerate: int, duration_sec: float) -> int:

@@ -1,5 +1,5 @@
 // scene_capi.cpp — C-ABI over the host scene model (librtscene.so): a scene builder that the Python
-// YAML front end (raytracer_amd/scene_yaml.py) and the tests drive, and the flattener that emits the
+// YAML front end (raytracer_amd/harness/scene_yaml.py) and the tests drive, and the flattener that emits the
 // `rt_scene_desc` tables of include/rtcore.h — the same tables the reference-side FFI crate would
 // emit from Scene::objects()/light_sources() (src/scene.rs:22-28) after compute_bvh() (src/scene.rs:38).
 #include <cstdio>
@@ -11,7 +11,7 @@
 #include <string>
 #include <vector>
 
-#include "../../include/rtcore.h"
+#include "../../../include/rtcore.h"
 #include "scene_model.hpp"
 
 using namespace rts;

@@ -7,7 +7,7 @@
 #include <sstream>
 #include <unordered_map>
 
-#include "../../include/rtcore.h"
+#include "../../../include/rtcore.h"
 
 namespace rts {
 

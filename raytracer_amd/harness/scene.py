@@ -2,7 +2,7 @@
 
 Names follow the reference: `SceneBuilder` (src/scene.rs:57-147), `Material` (src/scene/object/material.rs),
 `Camera` (src/scene/camera.rs), `Transformation`/`LocalTransformation` (src/math/transform*.rs).  All f64
-arithmetic happens in librtscene.so (raytracer_amd/host), which restates the reference operation by
+arithmetic happens in librtscene.so (raytracer_amd/harness/host), which restates the reference operation by
 operation; this module only marshals.  `SceneBuilder.flatten()` yields the `rt_scene_desc` tables of
 include/rtcore.h that the render core consumes.
 """
@@ -15,7 +15,7 @@ from typing import List, Optional, Sequence, Tuple
 
 import numpy as np
 
-from . import _native as N
+from .. import _native as N
 
 IDENTITY = (1., 0., 0., 0., 0., 1., 0., 0., 0., 0., 1., 0., 0., 0., 0., 1.)
 

@@ -16,7 +16,7 @@ from typing import Any, Dict, List, Optional
 
 import yaml
 
-from . import _native as N
+from .. import _native as N
 from . import scene as S
 
 

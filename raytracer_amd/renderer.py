@@ -12,7 +12,6 @@ from typing import Optional, Tuple
 import numpy as np
 
 from . import _native as N
-from .scene import FlatScene
 
 
 class RtError(RuntimeError):
@@ -31,9 +30,10 @@ def device_count() -> int:
 
 
 class DeviceScene:
-    """A flattened scene resident in device memory (`rt_scene`)."""
+    """A flattened scene resident in device memory (`rt_scene`).  `flat`: anything with a `.desc` (an `rt_scene_desc` and
+    whatever keeps its tables alive), e.g. harness.scene.FlatScene."""
 
-    def __init__(self, flat: FlatScene):
+    def __init__(self, flat):
         self._L = N.core_lib()
         self._h = C.c_void_p()
         _check(self._L.rt_scene_create(C.byref(flat.desc), C.byref(self._h)))
@@ -97,7 +97,7 @@ def quantize_device(d_rgb_ptr: int, n_values: int, d_out_ptr: int, stream: int =
     _check(N.core_lib().rt_quantize_device(C.c_void_p(d_rgb_ptr), n_values, C.c_void_p(d_out_ptr), C.c_void_p(stream)))
 
 
-def render(flat: FlatScene, camera: N.rt_camera, options: N.rt_options, want_stats: bool = True) -> Tuple[np.ndarray, Optional[dict]]:
+def render(flat, camera: N.rt_camera, options: N.rt_options, want_stats: bool = True) -> Tuple[np.ndarray, Optional[dict]]:
     """`Renderer::render` (renderer.rs:75-98) minus compute_bvh (done by `flatten`): one `rt_render` call.
     Returns (rgb[h, w, 3] f64, stats).  want_stats=False passes stats = NULL, which is the call the reference-side hook
     makes (ffi/hook.rs): the production kernels, no counters."""

@@ -26,7 +26,7 @@ def _ensure_built():
 _ensure_built()
 
 from raytracer_amd import _native as N  # noqa: E402
-from raytracer_amd import scene as S  # noqa: E402
+from raytracer_amd.harness import scene as S  # noqa: E402
 
 LOW_PREC = 1.0e-4  # assert_approx_eq_low_prec! (src/math/approx_eq.rs:2,22-36)
 FRAC_1_SQRT_2 = 0.7071067811865476

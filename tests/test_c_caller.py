@@ -36,7 +36,7 @@ def dump_scene(path, flat, cam, opt, n_devices=0):
 
 
 def _load(name, **kw):
-    from raytracer_amd import scene_yaml as Y
+    from raytracer_amd.harness import scene_yaml as Y
     rs = Y.load_scene(os.path.join(GOLDEN, "scenes", name + ".yml"), **kw)
     return rs.builder.flatten(), rs.camera, rs.options()
 

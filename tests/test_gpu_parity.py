@@ -16,7 +16,7 @@ import oracle as O
 from conftest import (FRAC_1_SQRT_2, GOLDEN, N, S, default_testing_builder, options_for_tests, translation)
 from raytracer_amd import distributed as D
 from raytracer_amd import renderer as R
-from raytracer_amd import scene_yaml as Y
+from raytracer_amd.harness import scene_yaml as Y
 
 pytestmark = pytest.mark.gpu
 
@@ -75,7 +75,7 @@ def test_animation_driver_frames_in_order_and_equal_to_single_frames():
     """AnimationRenderer::render_animation (animation_renderer.rs:109-122): frames prepared ahead on worker threads,
     rendered and quantised on the device, handed over in index order; each equals the frame rendered on its own
     (render_frame, :61-66), which is checked against the oracle."""
-    from raytracer_amd.animation import AnimationRenderer
+    from raytracer_amd.harness.animation import AnimationRenderer
     rs = Y.load_scene(scene_path("animations", "general/sphere"), width=100, height=100)
     anim = AnimationRenderer(rs, 12, 0.5)
     got = []

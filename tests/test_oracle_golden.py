@@ -11,7 +11,7 @@ from PIL import Image
 
 import oracle as O
 from conftest import GOLDEN
-from raytracer_amd import scene_yaml as Y
+from raytracer_amd.harness import scene_yaml as Y
 
 TEST_SCENES = ["chapters/cubes", "chapters/cylinders", "chapters/groups", "chapters/making-patterns", "chapters/making-scene",
                "chapters/planes", "chapters/reflections", "chapters/refractions", "chapters/shadows", "general/cover",

@@ -41,7 +41,7 @@ def _worker(rank, world, port, out_path):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle as O
-    from raytracer_amd import scene_yaml as Y
+    from raytracer_amd.harness import scene_yaml as Y
 
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)

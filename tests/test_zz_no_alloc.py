@@ -9,7 +9,7 @@ import pytest
 
 from conftest import GOLDEN, N, S
 from raytracer_amd import renderer as R
-from raytracer_amd import scene_yaml as Y
+from raytracer_amd.harness import scene_yaml as Y
 
 pytestmark = pytest.mark.gpu
 

@@ -6,8 +6,8 @@ import os
 import sys
 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
-from raytracer_amd import scene_yaml as Y  # noqa: E402
-from raytracer_amd.animation import AnimationRenderer  # noqa: E402
+from raytracer_amd.harness import scene_yaml as Y  # noqa: E402
+from raytracer_amd.harness.animation import AnimationRenderer  # noqa: E402
 
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
 name = sys.argv[1] if len(sys.argv) > 1 else "rotating-dragon"

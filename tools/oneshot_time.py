@@ -5,7 +5,7 @@ import time
 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 from raytracer_amd import renderer as R  # noqa: E402
-from raytracer_amd import scene_yaml as Y  # noqa: E402
+from raytracer_amd.harness import scene_yaml as Y  # noqa: E402
 
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
 for (w, h, ss) in ((800, 800, 2), (3840, 2160, 4)):

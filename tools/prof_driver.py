@@ -5,7 +5,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch
 from bench import WORKLOADS
-from raytracer_amd import renderer as R, scene_yaml as Y
+from raytracer_amd import renderer as R
+from raytracer_amd.harness import scene_yaml as Y
 wl = sys.argv[1] if len(sys.argv) > 1 else "dragons_4k_ss4_d5"
 frames = int(sys.argv[2]) if len(sys.argv) > 2 else 2
 path, w, h, ss, depth = WORKLOADS[wl]

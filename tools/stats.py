@@ -4,7 +4,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch
 from bench import WORKLOADS
-from raytracer_amd import renderer as R, scene_yaml as Y
+from raytracer_amd import renderer as R
+from raytracer_amd.harness import scene_yaml as Y
 for wl in (sys.argv[1:] or ["dragons_4k_ss4_d5"]):
     path, w, h, ss, depth = WORKLOADS[wl]
     rs = Y.load_scene(os.path.join(ROOT, path), width=w, height=h, depth=depth, supersampling_level=ss)

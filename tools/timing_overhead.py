@@ -7,7 +7,7 @@ import time
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import torch  # noqa: E402
 from raytracer_amd import renderer as R  # noqa: E402
-from raytracer_amd import scene_yaml as Y  # noqa: E402
+from raytracer_amd.harness import scene_yaml as Y  # noqa: E402
 
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
 rs = Y.load_scene(os.path.join(ROOT, "tests/golden/scenes/images/general/dragons.yml"), width=3840, height=2160, depth=5,
