@@ -31,6 +31,8 @@ FP64_PEAK_TFLOPS = 78.6   # MI355X_MICROARCH.md: vector FP64 peak (no matrix cor
 WORKLOADS = {
     # name: (scene file, width, height, supersampling level, depth)
     "dragons_4k_ss4_d5": ("tests/golden/scenes/images/general/dragons.yml", 3840, 2160, 4, 5),
+    "dragons_1080_ss4_d5": ("tests/golden/scenes/images/general/dragons.yml", 1920, 1080, 4, 5),
+    "dragons_1600_ss2_d5": ("tests/golden/scenes/images/general/dragons.yml", 1600, 1600, 2, 5),
     "dragons_800_ss2_d5": ("tests/golden/scenes/images/general/dragons.yml", 800, 800, 2, 5),
     "dragon_800_ss2_d5": ("scenes/dragon.yml", 800, 800, 2, 5),
     "csg_lens_800_ss2_d8": ("tests/golden/scenes/animations/general/csg-lens.yml", 800, 800, 2, 8),

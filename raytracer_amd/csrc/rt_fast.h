@@ -39,7 +39,7 @@ enum { MS_ALL = 7, MS_CLOSEST_CONTAINERS = 5, MS_SHADOW = 2 };
 
 // The ray being traversed and its collector (IntersectionCollector, intersection.rs:17-135, without the Vec).
 struct Trav {
-  d3 o, d, dinv;
+  d3 o, d;
   double limit;   // closest: t of the best hit so far; shadow: distance to the light; containers: 0 (only boxes entered at t <= 0)
   double t2;      // closest: smallest t of an intersection with any OTHER primitive than the hit (the runner-up)
   double a, b;    // closest: u, v of the hit; shadow: a = accumulated intensity; containers: largest negative t of the two innermost containers
@@ -52,8 +52,9 @@ struct Trav {
   uint32_t cur;   // reference being visited, RT_FREF_NONE when nothing is left to visit
   int sp;
   // The ray in f32, for the conservative slab test of the node step (box_keys_f32): t_f = fma(b, fdi, fno) with
-  // fdi = (float)dinv and fno = (float)-(o * dinv), per axis; ferr bounds what the roundings of fdi and fno can move t_f by
-  // (absolute part; the relative part is RT_SLAB_REL); limf = an f32 no less than near_limit(limit).
+  // fdi ~ 1 / d and fno ~ -o / d, per axis, both computed in f32; ferr bounds what their errors can move t_f by (absolute
+  // part; the relative part is RT_SLAB_REL); limf = an f32 no less than near_limit(limit).  The exact dir_inv of Ray::new
+  // (ray.rs:27-34) is not kept: only the slab test of axis-parallel rays and the cube read it, and they divide themselves.
   float fdx, fdy, fdz, fnx, fny, fnz, ferr, limf;
 };
 
@@ -66,38 +67,44 @@ struct Trav {
 #define RT_TIE_WINDOW 1.0e-10
 __device__ __forceinline__ double near_limit(double limit) { return limit + RT_TIE_WINDOW * fmax(1., limit); }
 
+#ifdef RT_HOST_EMU
+__device__ __forceinline__ float rcp_f32(float x) { return 1.0f / x; }
+#else
+__device__ __forceinline__ float rcp_f32(float x) { return __builtin_amdgcn_rcpf(x); }  // v_rcp_f32: 1 ulp
+#endif
+
 // An f32 no less than x (x > 0 or +inf): the nearest f32 moved up by at least its last bit.
 __device__ __forceinline__ float f32_above(double x) {
   float f = (float)x;
   return __builtin_fmaf(fabsf(f), 1.1920929e-07f, f);
 }
 
-// Relative and absolute slack of the f32 slab test (see box_keys_f32).  With u = 2^-24: t_f = fma(b, fdi, fno) differs
-// from the exact (b - o) * dinv by at most 2u |t| + 2u (1 + u) |o dinv| (fdi and fno are each one rounding away from
-// dinv and -o dinv, the fma adds one more); both parts are taken three times over, which also covers the roundings of
-// the slack arithmetic itself.
-#define RT_SLAB_REL 3.5762787e-07f  // 6u
+// Relative and absolute slack of the f32 slab test (see box_key_f32).  With u = 2^-24 (f32 unit roundoff): fdi = rcp((float)d)
+// is within 3u of 1 / d (one rounding of d, v_rcp_f32's 1 ulp <= 2u), fno = -(float)o * fdi within 5u of -o / d, and the fma
+// rounds once more, so t_f = fma(b, fdi, fno) differs from the exact (b - o) / d by at most 4u |t| + 8u |o / d| (using
+// |b / d| <= |t| + |o / d|).  Both parts are taken twice over, which also covers the roundings of the slack arithmetic
+// itself.
+#define RT_SLAB_REL 4.7683716e-07f  // 8u
+#define RT_SLAB_ABS 9.5367432e-07f  // 16u, times max |o / d|
 #define RT_SLAB_ABS_MIN 1.0e-30f    // floor of the absolute part (o = 0 makes it 0 otherwise)
 
 __device__ __forceinline__ void trav_start(Trav& T, d3 o, d3 d, uint32_t mode, double limit) {
   T.o = o;
   T.d = d;
-  T.dinv = mk3(1. / d.x, 1. / d.y, 1. / d.z);  // Ray::new (ray.rs:27-34)
   T.limit = limit;
   T.mode = mode;
   {
-    double px = o.x * T.dinv.x, py = o.y * T.dinv.y, pz = o.z * T.dinv.z;
-    T.fdx = (float)T.dinv.x;
-    T.fdy = (float)T.dinv.y;
-    T.fdz = (float)T.dinv.z;
-    T.fnx = (float)-px;
-    T.fny = (float)-py;
-    T.fnz = (float)-pz;
+    T.fdx = rcp_f32((float)d.x);
+    T.fdy = rcp_f32((float)d.y);
+    T.fdz = rcp_f32((float)d.z);
+    T.fnx = -(float)o.x * T.fdx;
+    T.fny = -(float)o.y * T.fdy;
+    T.fnz = -(float)o.z * T.fdz;
     float m = fmaxf(fmaxf(fabsf(T.fnx), fabsf(T.fny)), fabsf(T.fnz));
-    T.ferr = fmaxf(m * RT_SLAB_REL, RT_SLAB_ABS_MIN);
+    T.ferr = fmaxf(m * RT_SLAB_ABS, RT_SLAB_ABS_MIN);
     T.limf = f32_above(near_limit(limit));
-    // the f32 test needs all six finite (an axis-parallel ray has dinv = inf, and 0 * inf = NaN there is decided by the
-    // reference's operand order: such rays take the exact f64 test)
+    // the f32 test needs all six finite (an axis-parallel ray has 1 / d = inf, and 0 * inf = NaN there is decided by the
+    // reference's operand order: such rays take the exact f64 test).  (A component of d below f32's range counts as 0.)
     bool fin = fabsf(T.fdx) < INFINITY && fabsf(T.fdy) < INFINITY && fabsf(T.fdz) < INFINITY && m < INFINITY && T.ferr < INFINITY;
     T.odd = fin ? 0u : 1u;
   }
@@ -191,7 +198,7 @@ __device__ __forceinline__ void add_roots(const DevScene& s, Trav& T, uint32_t p
 template <bool STATS, int MS = MS_ALL>
 __device__ __forceinline__ void add_csg(const DevScene& s, Trav& T, uint32_t csg_root, Counters& cnt) {
   CsgHit list[RT_CSG_LIST_MAX];
-  int n = csg_survivors<STATS>(s, csg_root, T.o, T.d, T.dinv, list, cnt);
+  int n = csg_survivors<STATS>(s, csg_root, T.o, T.d, list, cnt);
   if (in_mode<MS>(T, M_CONTAINERS)) {
     // negative-t survivors, aggregated per leaf object (they all come from this one call)
     for (int i = 0; i < n; i++) {
@@ -297,7 +304,7 @@ template <int MS>
 __device__ __forceinline__ uint32_t box_key_f64(const Trav& T, const uint32_t* __restrict__ raw, int c, bool all_t, uint32_t ref) {
   double bb[6], tmin, tmax;
   for (int k = 0; k < 6; k++) bb[k] = (double)__uint_as_float(raw[6 * c + k]);
-  bool hit = box_times(bb, T.o, T.dinv, tmin, tmax);
+  bool hit = box_times(bb, T.o, mk3(1. / T.d.x, 1. / T.d.y, 1. / T.d.z), tmin, tmax);  // dir_inv of Ray::new (ray.rs:27-34)
   // a box can hold an accepted intersection only if it is entered no later than the limit (plus the window in which a
   // runner-up must still be seen, see near_limit) and, for t >= 0 intersections, is not entirely behind the origin
   bool h = hit & !(tmin > near_limit(T.limit)) & (all_t | !(tmax < 0.)) & (ref != RT_FREF_NONE);
@@ -360,6 +367,9 @@ __device__ __forceinline__ bool trav_busy(const Trav& T) { return T.cur != RT_FR
 // before any leaf is done).  Measured on the 4K frame: 8-16 equally good (38.95 -> 37.0 ms), 20 less so, 28 none.
 #ifndef RT_NODE_BREAK
 #define RT_NODE_BREAK 16
+#endif
+#ifndef RT_TRI_PREFETCH
+#define RT_TRI_PREFETCH 1  // fetch the next triangle of a leaf's run while this one is tested (20 more live registers)
 #endif
 
 // Runs the lane's traversal to completion (lanes that are not trav_busy have nothing to do).
@@ -467,7 +477,7 @@ __device__ __forceinline__ void trav_run(const DevScene& s, Trav& T, uint2* lds,
       double2 r0 = tp[0], r1 = tp[1], r2 = tp[2], r3 = tp[3], r4 = tp[4];
       for (uint32_t j = 0; j < count; j++) {
         double2 n0 = r0, n1 = r1, n2 = r2, n3 = r3, n4 = r4;
-        if (j + 1 < count) {
+        if (RT_TRI_PREFETCH && j + 1 < count) {
           tp += 5;
           n0 = tp[0];
           n1 = tp[1];
@@ -487,11 +497,20 @@ __device__ __forceinline__ void trav_run(const DevScene& s, Trav& T, uint2* lds,
           uint32_t material = in_mode<MS>(T, M_SHADOW) ? s.prim_info[prim].y : 0u;
           add_roots<STATS, MS>(s, T, prim, material, 1, &t, u, v);
         }
-        r0 = n0;
-        r1 = n1;
-        r2 = n2;
-        r3 = n3;
-        r4 = n4;
+        if (RT_TRI_PREFETCH) {
+          r0 = n0;
+          r1 = n1;
+          r2 = n2;
+          r3 = n3;
+          r4 = n4;
+        } else if (j + 1 < count) {
+          tp += 5;
+          r0 = tp[0];
+          r1 = tp[1];
+          r2 = tp[2];
+          r3 = tp[3];
+          r4 = tp[4];
+        }
       }
     } else {  // RT_FREF_PRIMS
       for (uint32_t j = 0; j < count; j++) {
@@ -508,12 +527,12 @@ __device__ __forceinline__ void trav_run(const DevScene& s, Trav& T, uint2* lds,
           pin_loaded(m0, m1, m2, m3, m4);
           const double inv[12] = {m0.x, m0.y, m1.x, m1.y, m2.x, m2.y, m3.x, m3.y, m4.x, m4.y, m5.x, m5.y};
           double ts[4], u, v;
-          int n = analytic_roots<STATS>(h0.y, h0.w, inv, yr.x, yr.y, T.o, T.d, T.dinv, ts, u, v, cnt);
+          int n = analytic_roots<STATS>(h0.y, h0.w, inv, yr.x, yr.y, T.o, T.d, ts, u, v, cnt);
           if (n) add_roots<STATS, MS>(s, T, idx, h0.z, n, ts, u, v);
         } else if ((ref >> RT_REF_KIND_SHIFT) == RT_REF_PRIM) {
           uint4 info = s.prim_info[idx];
           double ts[4], u, v;
-          int n = prim_roots<STATS>(s, info, T.o, T.d, T.dinv, ts, u, v, cnt);
+          int n = prim_roots<STATS>(s, info, T.o, T.d, ts, u, v, cnt);
           if (n) add_roots<STATS, MS>(s, T, idx, info.y, n, ts, u, v);
         } else if (CSG) {
           add_csg<STATS, MS>(s, T, idx, cnt);
@@ -653,7 +672,7 @@ __device__ __forceinline__ void run_machine(const DevScene& s, const DevOptions&
         if (T.p != RT_NONE && T.t2 <= near_limit(T.limit)) {  // coincident surfaces: settle the hit in the reference's order
           reforder::Coll c;
           reforder::coll_init_closest(c);
-          reforder::traverse<reforder::MODE_CLOSEST, STATS>(s, T.o, T.d, c, cnt);
+          reforder::traverse<reforder::MODE_CLOSEST, STATS>(s, T.o, T.d, c, cnt, near_limit(T.limit));
           T.p = c.hit_prim;
           T.limit = c.limit;
           T.a = c.hu;

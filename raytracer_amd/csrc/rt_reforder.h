@@ -97,9 +97,9 @@ __device__ __forceinline__ void coll_add_roots(const DevScene& s, Coll& c, uint3
 }
 
 template <int MODE, bool STATS>
-__device__ __forceinline__ void csg_intersect(const DevScene& s, uint32_t csg_root, d3 o, d3 d, d3 dinv, Coll& c, Counters& cnt) {
+__device__ __forceinline__ void csg_intersect(const DevScene& s, uint32_t csg_root, d3 o, d3 d, Coll& c, Counters& cnt) {
   CsgHit list[RT_CSG_LIST_MAX];
-  int n = csg_survivors<STATS>(s, csg_root, o, d, dinv, list, cnt);
+  int n = csg_survivors<STATS>(s, csg_root, o, d, list, cnt);
   // survivors -> outer collector, ascending t: collector.push(i) (csg.rs:119-121)
   if (MODE == MODE_CLOSEST) {
     int took = -1;
@@ -151,8 +151,15 @@ __device__ __forceinline__ void csg_intersect(const DevScene& s, uint32_t csg_ro
 // when t_enter >= hit_time(); its children are visited in REVERSE order, primitives/CSG intersected at once,
 // hit child groups pushed (so they pop in forward order).
 // ---------------------------------------------------------------------------------------------
+// `bound` (closest mode, the re-trace of rt_fast.h's coincident-surface rays): groups entered later than this are not
+// visited.  The caller knows the closest intersection's t up to the tie window (bound = near_limit(that t)); every
+// primitive of a group lies inside the group's box, so a group entered after `bound` holds only intersections beyond it:
+// none can be the hit, and none can make the reference skip a group that is entered before `bound` (group.rs:182 skips
+// when t_enter >= hit_time, and a hit_time such a primitive sets is > bound).  The groups entered up to `bound` are
+// therefore visited, skipped and intersected exactly as in the unbounded walk, and the hit is the same; what is saved is
+// the rest of the scene behind it, which the reference walks in tree order, not front to back.
 template <int MODE, bool STATS>
-__device__ __forceinline__ void traverse(const DevScene& s, d3 o, d3 d, Coll& c, Counters& cnt) {
+__device__ __forceinline__ void traverse(const DevScene& s, d3 o, d3 d, Coll& c, Counters& cnt, double bound = INFINITY) {
   uint32_t stk_begin[RT_STACK_MAX];
   uint32_t stk_count[RT_STACK_MAX];
   double stk_t[RT_STACK_MAX];
@@ -164,7 +171,7 @@ __device__ __forceinline__ void traverse(const DevScene& s, d3 o, d3 d, Coll& c,
     for (int k = 0; k < 6; k++) bb[k] = root->bb[k];
     double t;
     if (STATS) cnt.node_visits++;
-    if (!bbox_time(bb, o, dinv, t)) return;
+    if (!bbox_time(bb, o, dinv, t) || t > bound) return;
     stk_begin[0] = root->begin;
     stk_count[0] = root->count;
     stk_t[0] = t;
@@ -184,7 +191,7 @@ __device__ __forceinline__ void traverse(const DevScene& s, d3 o, d3 d, Coll& c,
         for (int k = 0; k < 6; k++) bb[k] = e->bb[k];
         double t;
         if (STATS) cnt.node_visits++;
-        if (bbox_time(bb, o, dinv, t)) {
+        if (bbox_time(bb, o, dinv, t) && !(t > bound)) {
           if (sp < RT_STACK_MAX) {
             stk_begin[sp] = e->begin;
             stk_count[sp] = e->count;
@@ -197,10 +204,10 @@ __device__ __forceinline__ void traverse(const DevScene& s, d3 o, d3 d, Coll& c,
       } else if (kind == RT_REF_PRIM) {
         uint4 info = s.prim_info[idx];
         double ts[4], u, v;
-        int n = prim_roots<STATS>(s, info, o, d, dinv, ts, u, v, cnt);
+        int n = prim_roots<STATS>(s, info, o, d, ts, u, v, cnt);
         if (n) coll_add_roots<MODE>(s, c, idx, info.y, n, ts, u, v);
       } else {
-        csg_intersect<MODE, STATS>(s, idx, o, d, dinv, c, cnt);
+        csg_intersect<MODE, STATS>(s, idx, o, d, c, cnt);
       }
     }
     if (MODE == MODE_SHADOW && c.intensity >= 1.) return;  // min(intensity, 1) is already 1 (intersection.rs:124-126)

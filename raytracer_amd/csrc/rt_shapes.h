@@ -155,8 +155,7 @@ __device__ __forceinline__ bool bbox_time(const double* bb, d3 o, d3 dinv, doubl
 
 // PrimitiveObject::intersect (object.rs:432-439) + Shape::local_intersect (shape.rs:51-62)
 template <bool STATS>
-__device__ __forceinline__ int prim_roots(const DevScene& s, uint4 info, d3 o, d3 d, d3 dinv, double* ts, double& u, double& v,
-                                          Counters& cnt) {
+__device__ __forceinline__ int prim_roots(const DevScene& s, uint4 info, d3 o, d3 d, double* ts, double& u, double& v, Counters& cnt) {
   uint32_t shape = info.x;
   u = -INFINITY;
   v = -INFINITY;
@@ -171,17 +170,16 @@ __device__ __forceinline__ int prim_roots(const DevScene& s, uint4 info, d3 o, d
     return n;
   }
   if (STATS) cnt.prim_tests++;
-  if (info.z != RT_NONE) {  // Ray::transform_new (ray.rs:21-23) -> Ray::new recomputes dir_inv (ray.rs:27-34)
+  if (info.z != RT_NONE) {  // Ray::transform_new (ray.rs:21-23)
     const double* m = s.xform_inv + (size_t)info.z * 16;
     o = mat_point(m, o);
     d = mat_vector(m, d);
-    dinv = mk3(1. / d.x, 1. / d.y, 1. / d.z);
   }
   switch (shape) {
     case RT_SHAPE_SPHERE: return sphere_roots(o, d, ts);
     case RT_SHAPE_PLANE: return plane_roots(o, d, ts);
     case RT_SHAPE_CUBE:
-    case RT_SHAPE_BBOX: return cube_roots(o, dinv, ts);
+    case RT_SHAPE_BBOX: return cube_roots(o, mk3(1. / d.x, 1. / d.y, 1. / d.z), ts);  // dir_inv of Ray::new (ray.rs:27-34), the only shape that reads it
     case RT_SHAPE_CYLINDER: {
       const double* q = s.quadric + (size_t)info.w * 2;
       return cylinder_roots(o, d, q[0], q[1], s.quadric_closed[info.w] != 0, ts);
@@ -196,20 +194,19 @@ __device__ __forceinline__ int prim_roots(const DevScene& s, uint4 info, d3 o, d
 // The same for an analytic primitive whose record is already in registers (DevLeafRec: rt_fast.h's PRIMS leaves).
 template <bool STATS>
 __device__ __forceinline__ int analytic_roots(uint32_t shape, uint32_t flags, const double* __restrict__ inv, double y_min, double y_max,
-                                              d3 o, d3 d, d3 dinv, double* ts, double& u, double& v, Counters& cnt) {
+                                              d3 o, d3 d, double* ts, double& u, double& v, Counters& cnt) {
   u = -INFINITY;
   v = -INFINITY;
   if (STATS) cnt.prim_tests++;
-  if (flags & RT_LEAFREC_XFORM) {  // Ray::transform_new (ray.rs:21-23) -> Ray::new recomputes dir_inv (ray.rs:27-34)
+  if (flags & RT_LEAFREC_XFORM) {  // Ray::transform_new (ray.rs:21-23)
     o = mat_point(inv, o);
     d = mat_vector(inv, d);
-    dinv = mk3(1. / d.x, 1. / d.y, 1. / d.z);
   }
   switch (shape) {
     case RT_SHAPE_SPHERE: return sphere_roots(o, d, ts);
     case RT_SHAPE_PLANE: return plane_roots(o, d, ts);
     case RT_SHAPE_CUBE:
-    case RT_SHAPE_BBOX: return cube_roots(o, dinv, ts);
+    case RT_SHAPE_BBOX: return cube_roots(o, mk3(1. / d.x, 1. / d.y, 1. / d.z), ts);  // dir_inv of Ray::new (ray.rs:27-34)
     case RT_SHAPE_CYLINDER: return cylinder_roots(o, d, y_min, y_max, (flags & RT_LEAFREC_CLOSED) != 0, ts);
     default: return cone_roots(o, d, y_min, y_max, (flags & RT_LEAFREC_CLOSED) != 0, ts);
   }
@@ -234,10 +231,10 @@ struct CsgHit {
 
 // One primitive's roots -> the level's collector: list[n..) and its closest positive t.
 template <bool STATS>
-__device__ __forceinline__ void csg_add_prim(const DevScene& s, uint32_t idx, d3 o, d3 d, d3 dinv, CsgHit* list, int& n, double& hit_time,
+__device__ __forceinline__ void csg_add_prim(const DevScene& s, uint32_t idx, d3 o, d3 d, CsgHit* list, int& n, double& hit_time,
                                              Counters& cnt) {
   double ts[4], u, v;
-  int k = prim_roots<STATS>(s, s.prim_info[idx], o, d, dinv, ts, u, v, cnt);
+  int k = prim_roots<STATS>(s, s.prim_info[idx], o, d, ts, u, v, cnt);
   for (int i = 0; i < k; i++) {
     if (sign_positive(ts[i]) && ts[i] < hit_time) hit_time = ts[i];
     if (n < RT_CSG_LIST_MAX) {
@@ -255,10 +252,11 @@ __device__ __forceinline__ void csg_add_prim(const DevScene& s, uint32_t idx, d3
 // ObjectGroup::intersect_iter (group.rs:171-201) for a group that is a CSG operand, into the level's collector.
 // `entry`: the group's DevEntry (rt_scene_create appends one per group operand).
 template <bool STATS>
-__device__ __forceinline__ void csg_add_group(const DevScene& s, uint32_t entry, d3 o, d3 d, d3 dinv, CsgHit* list, int& n,
+__device__ __forceinline__ void csg_add_group(const DevScene& s, uint32_t entry, d3 o, d3 d, CsgHit* list, int& n,
                                               double& hit_time, Counters& cnt) {
   uint32_t stk_begin[RT_CSG_GROUP_STACK], stk_count[RT_CSG_GROUP_STACK];
   double stk_t[RT_CSG_GROUP_STACK];
+  const d3 dinv = mk3(1. / d.x, 1. / d.y, 1. / d.z);  // Ray::new (ray.rs:27-34)
   int sp = 0;
   {
     const DevEntry* root = s.entries + entry;
@@ -293,7 +291,7 @@ __device__ __forceinline__ void csg_add_group(const DevScene& s, uint32_t entry,
           }
         }
       } else if (kind == RT_REF_PRIM) {
-        csg_add_prim<STATS>(s, idx, o, d, dinv, list, n, hit_time, cnt);
+        csg_add_prim<STATS>(s, idx, o, d, list, n, hit_time, cnt);
       }  // (a CSG object here is rejected by rt_scene_create)
     }
   }
@@ -301,7 +299,7 @@ __device__ __forceinline__ void csg_add_group(const DevScene& s, uint32_t entry,
 
 // Fills list[0..n) with the surviving intersections of the outermost CSG object `csg_root`, ascending t.
 template <bool STATS>
-__device__ __forceinline__ int csg_survivors(const DevScene& s, uint32_t csg_root, d3 o, d3 d, d3 dinv, CsgHit* list, Counters& cnt) {
+__device__ __forceinline__ int csg_survivors(const DevScene& s, uint32_t csg_root, d3 o, d3 d, CsgHit* list, Counters& cnt) {
   uint32_t f_csg[RT_CSG_NEST_MAX];
   uint8_t f_stage[RT_CSG_NEST_MAX];
   uint8_t f_start[RT_CSG_NEST_MAX];
@@ -318,9 +316,9 @@ __device__ __forceinline__ int csg_survivors(const DevScene& s, uint32_t csg_roo
       f_stage[fp]++;
       uint32_t kind = ref >> RT_REF_KIND_SHIFT, idx = ref & RT_REF_INDEX_MASK;
       if (kind == RT_REF_PRIM) {
-        csg_add_prim<STATS>(s, idx, o, d, dinv, list, n, f_hit[fp], cnt);
+        csg_add_prim<STATS>(s, idx, o, d, list, n, f_hit[fp], cnt);
       } else if (kind == RT_REF_NODE) {  // idx: the operand's DevEntry
-        csg_add_group<STATS>(s, idx, o, d, dinv, list, n, f_hit[fp], cnt);
+        csg_add_group<STATS>(s, idx, o, d, list, n, f_hit[fp], cnt);
       } else if (kind == RT_REF_CSG && fp + 1 < RT_CSG_NEST_MAX) {
         fp++;
         f_csg[fp] = idx;

@@ -17,7 +17,10 @@
 //     retrace         those few rays, settled in the reference's own visiting order (rt_reforder.h).
 //     shade           IntersecComputations::new for every hit (intersection.rs:217-256): one NODE record per hit
 //                     (over point, eye, normal, n1, n2), plus the reflected / refracted rays of level l+1.
-//   trace_shadow      one shadow ray per (node, light) for all nodes of all levels (integrator.rs:136-152).
+//     trace_shadow    one shadow ray per (node, light) for the nodes of the level (integrator.rs:136-152) — on a SECOND
+//                     stream, beside the next levels' trace / shade kernels: the deeper levels of a frame hold few rays and
+//                     leave most of the GPU idle (each launch still costs a dependent chain of ~150 node steps), and the
+//                     shadow rays, which nothing but the final combine waits for, fill it.
 //   level l = max_depth..0:
 //     combine         shade_hit_at_depth's fold over the lights (integrator.rs:199-228) for every node of the level, in
 //                     the reference's operation order; the colour goes to the parent node's reflected / refracted slot,
@@ -53,7 +56,7 @@ struct Ctrl {  // device-resident control block of one batch; zeroed when the ba
   uint32_t level_end[RT_LEVELS];   // nodes [level_end[l-1], level_end[l]) belong to level l
   uint32_t n_nodes;                // nodes allocated (may run past cap_nodes; clamped in level_end)
   uint32_t n_flagged;              // samples handed to the fallback
-  uint32_t shadow_fetch[9];        // trace_shadow: next (light, node) item in each XCD's share; [8]: used-up shares
+  uint32_t shadow_fetch[RT_LEVELS][9];  // trace_shadow of each level: next (light, node) item in each XCD's share; [8]: used-up shares
 };
 
 struct Ws {  // workspace of one batch (device pointers; owned by rt_scene)
@@ -361,6 +364,7 @@ __global__ __launch_bounds__(64, RT_CLOSEST_WAVES) void trace_closest_kernel(Dev
         } else if (T.t2 <= fast::near_limit(T.limit)) {  // coincident surfaces: settled by the retrace kernel
           uint32_t k = atomicAdd(&w.ctrl->n_retrace[level], 1u);
           w.retrace[k] = my;
+          w.hit_f[my] = T.limit;  // (the ray's t slot: how far the retrace has to look, reforder::traverse's bound)
           my = RT_NONE;
         } else {
           if (s.prim_flags[T.p] & 1u) {  // a transparent material (one byte instead of the prim_info -> material chain)
@@ -412,7 +416,7 @@ __global__ __launch_bounds__(64, 2) void retrace_kernel(DevScene s, rt_camera ca
     }
     reforder::Coll c;
     reforder::coll_init_closest(c);
-    reforder::traverse<reforder::MODE_CLOSEST, STATS>(s, o, d, c, cnt);
+    reforder::traverse<reforder::MODE_CLOSEST, STATS>(s, o, d, c, cnt, fast::near_limit(w.hit_f[id]));
     if (STATS) cnt.retraced++;
     double n1 = 1.0, n2 = 1.0;
     if (c.hit_prim != RT_NONE) {
@@ -669,14 +673,16 @@ __device__ __forceinline__ bool shadow_start(const DevScene& s, fast::Trav& T, d
 }
 
 template <bool STATS, bool CSG>
-__global__ __launch_bounds__(64, RT_TRACE_WAVES) void trace_shadow_kernel(DevScene s, Ws w, unsigned long long* stats,
-                                                                         uint32_t* overflow_flag) {
+__global__ __launch_bounds__(64, RT_TRACE_WAVES) void trace_shadow_kernel(DevScene s, Ws w, uint32_t level, uint32_t last_level,
+                                                                         unsigned long long* stats, uint32_t* overflow_flag) {
   __shared__ uint2 lds_stack[RT_LDS_STACK * 64];
   uint2* lds = lds_stack + (threadIdx.x & 63u);
   uint2 ovf[RT_OVF_STACK];
   Counters cnt = {};
   const unsigned long long clk0 = STATS ? (unsigned long long)clock64() : 0ull;
-  const uint32_t n_nodes = w.ctrl->n_nodes, n_items = n_nodes * s.n_lights;  // (< 2^32: ensure_workspace)
+  // the nodes of levels level..last_level (close_level_kernel has recorded where each level's nodes end)
+  const uint32_t node0 = level == 0 ? 0u : w.ctrl->level_end[level - 1];
+  const uint32_t n_nodes = w.ctrl->level_end[last_level] - node0, n_items = n_nodes * s.n_lights;  // (< 2^32: ensure_workspace)
   const size_t cap = w.cap_nodes;
   fast::Trav T;
   T.cur = RT_FREF_NONE;
@@ -690,11 +696,11 @@ __global__ __launch_bounds__(64, RT_TRACE_WAVES) void trace_shadow_kernel(DevSce
   for (;;) {
     bool want = my == RT_NONE && !exhausted;
     if (__builtin_amdgcn_ballot_w64(want) != 0ull) {
-      uint32_t id = xcd_take(w.ctrl->shadow_fetch, n_items, cursor, want);
+      uint32_t id = xcd_take(w.ctrl->shadow_fetch[level], n_items, cursor, want);
       if (want) {
         if (id != RT_NONE) {
           light = id / n_nodes;
-          my = id - light * n_nodes;
+          my = node0 + (id - light * n_nodes);
           const double* nf = w.node_f + my;
           d3 over = mk3(nf[(NF_OVER + 0) * cap], nf[(NF_OVER + 1) * cap], nf[(NF_OVER + 2) * cap]);
           d3 normal = mk3(nf[(NF_NORMAL + 0) * cap], nf[(NF_NORMAL + 1) * cap], nf[(NF_NORMAL + 2) * cap]);

@@ -5,7 +5,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'oracle'))
 import numpy as np
 from PIL import Image
-from raytracer_amd.harness import scene_yaml as Y, renderer as R
+from raytracer_amd import renderer as R
+from raytracer_amd.harness import scene_yaml as Y
 import oracle as O
 
 names = [a for a in sys.argv[1:] if not a.startswith('-')]
