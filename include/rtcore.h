@@ -218,7 +218,9 @@ typedef struct rt_stats {
                               re-rendered by the single-kernel state machine (same pixels, slower).  0 in a well-sized batch */
   double ms_upload, ms_kernel, ms_download;
   double ms_trace_closest, ms_retrace, ms_shade, ms_trace_shadow, ms_combine, ms_other; /* rt_options.timing: GPU time of the
-                              streamed pipeline's launches by kernel class, HIP events on the render's stream, summed over the frame */
+                              streamed pipeline's launches by kernel class, HIP events around each launch, summed over the frame.
+                              Small batches run level 0's shadow rays on a second stream beside the deeper levels' kernels:
+                              ms_trace_shadow then overlaps the other classes, and the sum of the classes can exceed ms_kernel */
 } rt_stats;
 
 /* ---- library ------------------------------------------------------------------------------ */

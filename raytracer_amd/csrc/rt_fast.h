@@ -105,7 +105,10 @@ __device__ __forceinline__ void trav_start(Trav& T, d3 o, d3 d, uint32_t mode, d
     T.limf = f32_above(near_limit(limit));
     // the f32 test needs all six finite (an axis-parallel ray has 1 / d = inf, and 0 * inf = NaN there is decided by the
     // reference's operand order: such rays take the exact f64 test).  (A component of d below f32's range counts as 0.)
-    bool fin = fabsf(T.fdx) < INFINITY && fabsf(T.fdy) < INFINITY && fabsf(T.fdz) < INFINITY && m < INFINITY && T.ferr < INFINITY;
+    // (below 1e18 rather than merely finite: a grid step of up to 1e16 times fdi must not overflow, box coordinates being
+    // at most 1e18, rt_scene_create)
+    const float big = 1.0e18f;
+    bool fin = fabsf(T.fdx) < big && fabsf(T.fdy) < big && fabsf(T.fdz) < big && m < big;
     T.odd = fin ? 0u : 1u;
   }
   T.cur = RT_MAKE_FREF(RT_FREF_INNER, 0, 0);
@@ -311,6 +314,53 @@ __device__ __forceinline__ uint32_t box_key_f64(const Trav& T, const uint32_t* _
   return h ? __float_as_uint(fmaxf(key_below(tmin), RT_KEY_MIN)) : RT_KEY_NONE;
 }
 
+#if RT_QNODE
+// The same two tests on a quantised node (rt_device.h): box coordinate = org + q * step per axis, so
+//     t_f = fma(q, A, B)   with   A = step * fdi (exact: step is a power of two),   B = fma(org, fdi, fno)   per node and axis.
+// B carries the roundings of fdi and fno scaled by the origin plane's distance: 3u |org / d| + 5u |o / d| + u |B|, and
+// |org / d| <= |B| + |o / d|; with the 3u (|t| + |B|) of q A and the fma's own u |t| that is 4u |t| + 7u |B| + 8u |o / d|
+// in all: the relative and the per-ray slack as before, plus RT_SLAB_NODE max |B| per node (all taken twice over).
+#define RT_SLAB_NODE 9.5367432e-07f  // 16u
+struct QNodeF32 {
+  float ax, ay, az, bx, by, bz, err;
+};
+__device__ __forceinline__ float grid_step(uint32_t exps, int axis) { return __uint_as_float(((exps >> (8 * axis)) & 0xFFu) << 23); }
+__device__ __forceinline__ QNodeF32 qnode_f32(const Trav& T, uint4 head) {
+  QNodeF32 n;
+  n.ax = grid_step(head.w, 0) * T.fdx;
+  n.ay = grid_step(head.w, 1) * T.fdy;
+  n.az = grid_step(head.w, 2) * T.fdz;
+  n.bx = __builtin_fmaf(__uint_as_float(head.x), T.fdx, T.fnx);
+  n.by = __builtin_fmaf(__uint_as_float(head.y), T.fdy, T.fny);
+  n.bz = __builtin_fmaf(__uint_as_float(head.z), T.fdz, T.fnz);
+  n.err = __builtin_fmaf(fmaxf(fmaxf(fabsf(n.bx), fabsf(n.by)), fabsf(n.bz)), RT_SLAB_NODE, T.ferr);
+  return n;
+}
+__device__ __forceinline__ float qcoord(uint32_t word, int c) { return (float)((word >> (8 * c)) & 0xFFu); }  // v_cvt_f32_ubyteN
+__device__ __forceinline__ uint32_t qbox_key_f32(const Trav& T, const QNodeF32& n, const uint32_t* __restrict__ qc, int c, float floorv,
+                                                 uint32_t ref) {
+  const float x0 = __builtin_fmaf(qcoord(qc[0], c), n.ax, n.bx), x1 = __builtin_fmaf(qcoord(qc[3], c), n.ax, n.bx);
+  const float y0 = __builtin_fmaf(qcoord(qc[1], c), n.ay, n.by), y1 = __builtin_fmaf(qcoord(qc[4], c), n.ay, n.by);
+  const float z0 = __builtin_fmaf(qcoord(qc[2], c), n.az, n.bz), z1 = __builtin_fmaf(qcoord(qc[5], c), n.az, n.bz);
+  const float entry = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fminf(z0, z1));
+  const float exit_ = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fmaxf(z0, z1));
+  const float lo = __builtin_fmaf(-fabsf(entry), RT_SLAB_REL, entry) - n.err;
+  const float hi = __builtin_fmaf(fabsf(exit_), RT_SLAB_REL, exit_) + n.err;
+  const bool visit = !(fmaxf(lo, floorv) > fminf(hi, T.limf)) & (ref != RT_FREF_NONE);
+  return visit ? __float_as_uint(fmaxf(lo, RT_KEY_MIN)) : RT_KEY_NONE;
+}
+template <int MS>
+__device__ __forceinline__ uint32_t qbox_key_f64(const Trav& T, uint4 head, const uint32_t* __restrict__ qc, int c, bool all_t, uint32_t ref) {
+  double bb[6], tmin, tmax;
+  for (int k = 0; k < 6; k++)  // org + q * step: exact in f64 (quantize_node)
+    bb[k] = (double)__uint_as_float(k % 3 == 0 ? head.x : (k % 3 == 1 ? head.y : head.z)) +
+            (double)((qc[k] >> (8 * c)) & 0xFFu) * (double)grid_step(head.w, k % 3);
+  bool hit = box_times(bb, T.o, mk3(1. / T.d.x, 1. / T.d.y, 1. / T.d.z), tmin, tmax);  // dir_inv of Ray::new (ray.rs:27-34)
+  bool h = hit & !(tmin > near_limit(T.limit)) & (all_t | !(tmax < 0.)) & (ref != RT_FREF_NONE);
+  return h ? __float_as_uint(fmaxf(key_below(tmin), RT_KEY_MIN)) : RT_KEY_NONE;
+}
+#endif
+
 // A stack entry: reference in the low word, key (f32 bits, a lower bound of the entry time) in the high word.
 __device__ __forceinline__ double pack_entry(uint32_t ref, uint32_t key_bits) {
   return __longlong_as_double((long long)(((unsigned long long)key_bits << 32) | ref));
@@ -397,6 +447,28 @@ __device__ __forceinline__ void trav_run(const DevScene& s, Trav& T, uint2* lds,
       if (STATS) count_step(cnt);
       // The whole node is fetched first (16-B loads, all in flight together), then tested: written out by hand because
       // the compiler otherwise fetches and waits box by box.
+      const bool all_t = in_mode<MS>(T, M_CONTAINERS);
+      double ent[4];
+#if RT_QNODE
+      const uint4* np = reinterpret_cast<const uint4*>(s.nodes + (T.cur & RT_FREF_INDEX_MASK));
+      const uint4 head = np[0], refs = np[1], qa = np[2];
+      const uint2 qb = *reinterpret_cast<const uint2*>(np + 3);
+      const uint32_t ref4[4] = {refs.x, refs.y, refs.z, refs.w};
+      const uint32_t qc[6] = {qa.x, qa.y, qa.z, qa.w, qb.x, qb.y};
+      if (__builtin_amdgcn_ballot_w64(T.odd != 0u) == 0ull) {  // wave-uniform: a real branch
+        const float floorv = all_t ? -INFINITY : 0.f;
+        const QNodeF32 qn = qnode_f32(T, head);
+        for (int c = 0; c < 4; c++) {
+          if (STATS && ref4[c] != RT_FREF_NONE) cnt.node_visits++;
+          ent[c] = pack_entry(ref4[c], qbox_key_f32(T, qn, qc, c, floorv, ref4[c]));
+        }
+      } else {  // some lane's ray is parallel to an axis: the reference's operand order decides what 0 * inf does
+        for (int c = 0; c < 4; c++) {
+          if (STATS && ref4[c] != RT_FREF_NONE) cnt.node_visits++;
+          ent[c] = pack_entry(ref4[c], qbox_key_f64<MS>(T, head, qc, c, all_t, ref4[c]));
+        }
+      }
+#else
       const uint4* np = reinterpret_cast<const uint4*>(s.nodes + (T.cur & RT_FREF_INDEX_MASK));
       constexpr int NQ = 7;
       uint4 q[NQ];
@@ -408,8 +480,6 @@ __device__ __forceinline__ void trav_run(const DevScene& s, Trav& T, uint2* lds,
         raw[4 * k + 2] = q[k].z;
         raw[4 * k + 3] = q[k].w;
       }
-      const bool all_t = in_mode<MS>(T, M_CONTAINERS);
-      double ent[4];
       if (__builtin_amdgcn_ballot_w64(T.odd != 0u) == 0ull) {  // wave-uniform: a real branch
         const float floorv = all_t ? -INFINITY : 0.f;
         for (int c = 0; c < 4; c++) {
@@ -424,6 +494,7 @@ __device__ __forceinline__ void trav_run(const DevScene& s, Trav& T, uint2* lds,
           ent[c] = pack_entry(ref, box_key_f64<MS>(T, raw, c, all_t, ref));
         }
       }
+#endif
       if (MS != MS_SHADOW || RT_SHADOW_SORT) {
         // nearest child first: sort the four entries ascending by key (5 compare-exchanges).  An entry read as an f64 is a
         // positive normal number whose order is the order of (key, ref) as a u64, so an exchange is v_min_f64 + v_max_f64.
@@ -521,10 +592,15 @@ __device__ __forceinline__ void trav_run(const DevScene& s, Trav& T, uint2* lds,
                 m2 = reinterpret_cast<const double2*>(rp)[3], m3 = reinterpret_cast<const double2*>(rp)[4],
                 m4 = reinterpret_cast<const double2*>(rp)[5], m5 = reinterpret_cast<const double2*>(rp)[6],
                 yr = reinterpret_cast<const double2*>(rp)[7];
+#ifndef RT_HOST_EMU
+        // (all eight loads are issued here, before the flags are looked at: the compiler otherwise fetches the header,
+        // waits, branches and only then fetches the matrix — two memory round trips per primitive instead of one)
+        asm volatile("" : "+v"(h0.x), "+v"(h0.y), "+v"(h0.z), "+v"(h0.w), "+v"(m0.x), "+v"(m0.y), "+v"(m1.x), "+v"(m1.y), "+v"(m2.x),
+                          "+v"(m2.y), "+v"(m3.x), "+v"(m3.y), "+v"(m4.x), "+v"(m4.y), "+v"(m5.x), "+v"(m5.y), "+v"(yr.x), "+v"(yr.y));
+#endif
         uint32_t ref = h0.x;
         uint32_t idx = ref & RT_REF_INDEX_MASK;
         if (h0.w & RT_LEAFREC_INLINE) {
-          pin_loaded(m0, m1, m2, m3, m4);
           const double inv[12] = {m0.x, m0.y, m1.x, m1.y, m2.x, m2.y, m3.x, m3.y, m4.x, m4.y, m5.x, m5.y};
           double ts[4], u, v;
           int n = analytic_roots<STATS>(h0.y, h0.w, inv, yr.x, yr.y, T.o, T.d, ts, u, v, cnt);

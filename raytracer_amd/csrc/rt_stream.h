@@ -36,6 +36,9 @@
 
 namespace stream {
 
+#ifndef RT_STREAM_NT
+#define RT_STREAM_NT 1
+#endif
 #define RT_RAY_STRIDE 8  // doubles per queued ray: origin, direction, (parent, root) as two u32, one spare
 #define RT_HIT_FIELDS 5  // doubles per hit: t, u, v, n1, n2 (the primitive is kept apart: a miss writes and reads 4 bytes)
 #define RT_LEVELS (RT_MAX_DEPTH + 1)
@@ -184,6 +187,15 @@ __device__ __forceinline__ uint32_t xcd_take(uint32_t* counters, uint32_t n_item
   return id;
 }
 
+// Streamed once, never re-read by this kernel: loads and stores of the ray queues and of the hit / node / shadow records carry
+// the non-temporal hint, so that they do not push the scene's nodes and triangles (what the traversal re-reads) out of L2.
+#if RT_STREAM_NT && !defined(RT_HOST_EMU)
+template <class T> __device__ __forceinline__ T ld_stream(const T* p) { return __builtin_nontemporal_load(p); }
+template <class T> __device__ __forceinline__ void st_stream(T* p, T v) { __builtin_nontemporal_store(v, p); }
+#else
+template <class T> __device__ __forceinline__ T ld_stream(const T* p) { return *p; }
+template <class T> __device__ __forceinline__ void st_stream(T* p, T v) { *p = v; }
+#endif
 __device__ __forceinline__ uint64_t dbits(double d) { return (uint64_t)__double_as_longlong(d); }
 __device__ __forceinline__ double bitsd(uint64_t u) { return __longlong_as_double((long long)u); }
 
@@ -247,9 +259,9 @@ __device__ __forceinline__ bool first_ray(const rt_camera& cam, const DevOptions
 
 __device__ __forceinline__ void load_ray(const double* __restrict__ q, uint32_t id, d3& o, d3& d, uint32_t& parent, uint32_t& root) {
   const double* r = q + (size_t)id * RT_RAY_STRIDE;
-  o = mk3(r[0], r[1], r[2]);
-  d = mk3(r[3], r[4], r[5]);
-  uint64_t link = dbits(r[6]);
+  o = mk3(ld_stream(r + 0), ld_stream(r + 1), ld_stream(r + 2));
+  d = mk3(ld_stream(r + 3), ld_stream(r + 4), ld_stream(r + 5));
+  uint64_t link = dbits(ld_stream(r + 6));
   parent = (uint32_t)link;
   root = (uint32_t)(link >> 32);
 }
@@ -266,7 +278,7 @@ __device__ __forceinline__ void store_ray(double* __restrict__ q, uint32_t id, d
 
 __device__ __forceinline__ void store_hit(const Ws& w, uint32_t level, uint32_t id, uint32_t prim, double t, double u, double v,
                                           double n1, double n2) {
-  w.hit_prim[level ? 1 : 0][id] = prim;
+  w.hit_prim[level ? 1 : 0][id] = prim;  // (plain stores: the shade kernel reads the hits right after this kernel)
   if (prim != RT_NONE) {
     double* h = w.hit_f + id;
     const size_t cap = w.cap_rays;
@@ -702,13 +714,13 @@ __global__ __launch_bounds__(64, RT_TRACE_WAVES) void trace_shadow_kernel(DevSce
           light = id / n_nodes;
           my = node0 + (id - light * n_nodes);
           const double* nf = w.node_f + my;
-          d3 over = mk3(nf[(NF_OVER + 0) * cap], nf[(NF_OVER + 1) * cap], nf[(NF_OVER + 2) * cap]);
-          d3 normal = mk3(nf[(NF_NORMAL + 0) * cap], nf[(NF_NORMAL + 1) * cap], nf[(NF_NORMAL + 2) * cap]);
+          d3 over = mk3(ld_stream(nf + (NF_OVER + 0) * cap), ld_stream(nf + (NF_OVER + 1) * cap), ld_stream(nf + (NF_OVER + 2) * cap));
+          d3 normal = mk3(ld_stream(nf + (NF_NORMAL + 0) * cap), ld_stream(nf + (NF_NORMAL + 1) * cap), ld_stream(nf + (NF_NORMAL + 2) * cap));
           if (shadow_start(s, T, over, normal, light)) {
             if (STATS) cnt.rays_shadow++;
           } else {  // the light is behind the surface: no ray
             if (STATS) cnt.shadow_culled++;
-            w.shadow[(size_t)light * cap + my] = 0.;
+            st_stream(&w.shadow[(size_t)light * cap + my], 0.);
             my = RT_NONE;
           }
         } else {
@@ -723,7 +735,7 @@ __global__ __launch_bounds__(64, RT_TRACE_WAVES) void trace_shadow_kernel(DevSce
     uint32_t min_active = __builtin_amdgcn_ballot_w64(exhausted) != 0ull ? 0u : (uint32_t)RT_REFILL_BELOW;
     fast::trav_run<STATS, fast::MS_SHADOW, CSG>(s, T, lds, ovf, cnt, min_active);
     if (my != RT_NONE && !fast::trav_busy(T)) {
-      w.shadow[(size_t)light * cap + my] = T.a;
+      st_stream(&w.shadow[(size_t)light * cap + my], T.a);
       my = RT_NONE;
     }
   }

@@ -602,6 +602,57 @@ struct FastLayout {
   std::string error;
 };
 
+#if RT_QNODE
+// Quantises the boxes of a wide node's children onto the node's grid (rt_device.h): every quantised box contains the
+// reference's f64 box (checked in exact arithmetic: origin + q * step is exact in f64 by the choice of the step).
+// false: a coordinate is not finite or beyond 1e18 (the reference clamps infinite shapes to 1e7, bounding_box.rs:154-157).
+bool quantize_node(DevNode& n, const double (*bb)[6], int count) {
+  n.exps = 0;
+  for (int k = 0; k < 6; k++) n.q[k] = 0;
+  for (int a = 0; a < 3; a++) {
+    double lo = INFINITY, hi = -INFINITY;
+    for (int c = 0; c < count; c++) {
+      if (!(std::fabs(bb[c][a]) <= 1e18) || !(std::fabs(bb[c][a + 3]) <= 1e18)) return false;
+      lo = std::min(lo, bb[c][a]);
+      hi = std::max(hi, bb[c][a + 3]);
+    }
+    if (count == 0) lo = hi = 0.;
+    float org = (float)lo;
+    if ((double)org > lo) org = std::nextafterf(org, -INFINITY);
+    // step = 2^e: 255 steps reach the largest maximum; never finer than 2^-40 of the origin (so that origin + q * step is
+    // exact in f64) nor than 2^-100
+    int e = -100;
+    if (org != 0.f) e = std::max(e, std::ilogb((double)org) - 40);
+    double extent = hi - (double)org;
+    if (extent > 0.) e = std::max(e, (int)std::ceil(std::log2(extent / 255.)) - 1);
+    for (;; e++) {
+      const double step = std::ldexp(1., e);
+      bool ok = true;
+      uint32_t ql[RT_NODE_WIDTH] = {}, qh[RT_NODE_WIDTH] = {};
+      for (int c = 0; c < count && ok; c++) {
+        double l = std::floor((bb[c][a] - (double)org) / step), h = std::ceil((bb[c][a + 3] - (double)org) / step);
+        l = std::min(std::max(l, 0.), 255.);
+        h = std::max(h, 0.);
+        while (l > 0. && (double)org + l * step > bb[c][a]) l -= 1.;
+        while (h <= 255. && (double)org + h * step < bb[c][a + 3]) h += 1.;
+        if (h > 255. || (double)org + l * step > bb[c][a]) ok = false;
+        ql[c] = (uint32_t)l;
+        qh[c] = (uint32_t)h;
+      }
+      if (!ok) continue;
+      if (e + 127 < 1 || e + 127 > 254) return false;
+      n.org[a] = org;
+      n.exps |= (uint32_t)(e + 127) << (8 * a);
+      for (int c = 0; c < count; c++) {
+        n.q[a] |= ql[c] << (8 * c);
+        n.q[a + 3] |= qh[c] << (8 * c);
+      }
+      break;
+    }
+  }
+  return true;
+}
+#else
 // The reference's f64 box, rounded outward to the node's f32 fields (min down, max up): a superset of the box.
 void set_node_box(DevNode& n, int child, const double* bb) {
   for (int k = 0; k < 6; k++) {
@@ -614,6 +665,7 @@ void set_node_box(DevNode& n, int child, const double* bb) {
     n.bb[child][k] = f;
   }
 }
+#endif
 
 struct FastItem {  // how a parent refers to one child: reference + the box tested before entering it
   uint32_t ref;
@@ -826,12 +878,24 @@ void fold_nodes(FastLayout& L) {
     std::memset(&n, 0, sizeof(n));
     uint32_t held = t.held + (slots.empty() ? 0u : (uint32_t)slots.size() - 1u);
     if (held > L.stack_need) L.stack_need = held;
+#if RT_QNODE
+    {
+      double boxes[RT_NODE_WIDTH][6];
+      for (size_t i = 0; i < slots.size(); i++) std::memcpy(boxes[i], slots[i].bb, sizeof(boxes[i]));
+      if (!quantize_node(n, boxes, (int)slots.size())) {
+        L.error = "a bounding box coordinate is not finite or beyond 1e18";
+        return;
+      }
+    }
+#endif
     for (int i = 0; i < RT_NODE_WIDTH; i++) {
       if ((size_t)i >= slots.size()) {
         n.ref[i] = RT_FREF_NONE;
         continue;
       }
+#if !RT_QNODE
       set_node_box(n, i, slots[i].bb);
+#endif
       if (inner(slots[i].ref)) {
         uint32_t wide = (uint32_t)L.nodes.size();
         L.nodes.emplace_back();
@@ -860,6 +924,7 @@ bool build_fast_layout(const rt_scene_desc* d, FastLayout& L) {
   n.ref[1] = RT_FREF_NONE;
   L.bin[0] = n;
   fold_nodes(L);
+  if (!L.error.empty()) return false;
   // triangles outside triangle-only leaves (mixed leaves, CSG operands) still need a slot in the triangle tables
   for (uint32_t i = 0; i < d->n_prims; i++) {
     uint8_t sh = d->prim_shape[i];

@@ -576,4 +576,5 @@ def test_timing_mode_reports_kernel_classes():
     assert torch.equal(out, ref)
     assert st["launches_trace_shadow"] >= 1 and st["launches_trace_closest"] >= opt.max_depth + 1
     parts = sum(st[k] for k in ("ms_trace_closest", "ms_retrace", "ms_shade", "ms_trace_shadow", "ms_combine", "ms_other"))
-    assert 0 < parts <= st["ms_kernel"] * 1.05
+    # (a batch this small runs level 0's shadow rays on the side stream, beside the other classes: include/rtcore.h, rt_stats)
+    assert 0 < parts - st["ms_trace_shadow"] <= st["ms_kernel"] * 1.05 and 0 < st["ms_trace_shadow"] <= st["ms_kernel"] * 1.05
