@@ -288,7 +288,9 @@ __device__ __forceinline__ float key_below(double t) {
 #define RT_KEY_MIN 1.17549435e-38f
 #define RT_KEY_NONE 0x7F800000u  // bits of +inf
 
-__device__ __forceinline__ uint32_t box_key_f32(const Trav& T, const uint32_t* __restrict__ raw, int c, float floorv, uint32_t ref) {
+// (v_pk_fma_f32 for the six fmas — two planes of an axis per instruction — was measured slower: 36.5 against 35.4 ms for the
+// 4K frame; the packed instruction saves no issue time on this part and its register pairs cost the shadow kernel spills)
+__device__ __forceinline__ bool box_test_f32(const Trav& T, const uint32_t* __restrict__ raw, int c, float floorv, uint32_t ref, float& lo) {
   const float b0 = __uint_as_float(raw[6 * c + 0]), b1 = __uint_as_float(raw[6 * c + 1]), b2 = __uint_as_float(raw[6 * c + 2]);
   const float b3 = __uint_as_float(raw[6 * c + 3]), b4 = __uint_as_float(raw[6 * c + 4]), b5 = __uint_as_float(raw[6 * c + 5]);
   const float x0 = __builtin_fmaf(b0, T.fdx, T.fnx), x1 = __builtin_fmaf(b3, T.fdx, T.fnx);
@@ -296,9 +298,13 @@ __device__ __forceinline__ uint32_t box_key_f32(const Trav& T, const uint32_t* _
   const float z0 = __builtin_fmaf(b2, T.fdz, T.fnz), z1 = __builtin_fmaf(b5, T.fdz, T.fnz);
   const float entry = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fminf(z0, z1));
   const float exit_ = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fmaxf(z0, z1));
-  const float lo = __builtin_fmaf(-fabsf(entry), RT_SLAB_REL, entry) - T.ferr;
+  lo = __builtin_fmaf(-fabsf(entry), RT_SLAB_REL, entry) - T.ferr;
   const float hi = __builtin_fmaf(fabsf(exit_), RT_SLAB_REL, exit_) + T.ferr;
-  const bool visit = !(fmaxf(lo, floorv) > fminf(hi, T.limf)) & (ref != RT_FREF_NONE);
+  return !(fmaxf(lo, floorv) > fminf(hi, T.limf)) & (ref != RT_FREF_NONE);
+}
+__device__ __forceinline__ uint32_t box_key_f32(const Trav& T, const uint32_t* __restrict__ raw, int c, float floorv, uint32_t ref) {
+  float lo;
+  const bool visit = box_test_f32(T, raw, c, floorv, ref, lo);
   return visit ? __float_as_uint(fmaxf(lo, RT_KEY_MIN)) : RT_KEY_NONE;
 }
 
@@ -379,6 +385,16 @@ __device__ __forceinline__ void stack_push(Trav& T, uint2* lds, uint2* ovf, doub
     ovf[i].y = entry_key(entry);                         // the array)
   }
   T.sp++;
+}
+
+// The push without a branch: the entry is written to the slot above the top either way and only counted when `valid`.
+// The caller has checked (for the whole wavefront) that the slot is one of the LDS part.
+#ifndef RT_PUSH_BRANCHLESS
+#define RT_PUSH_BRANCHLESS 1
+#endif
+__device__ __forceinline__ void stack_push_if(Trav& T, uint2* lds, double entry, bool valid) {
+  *reinterpret_cast<double*>(&lds[T.sp * 64]) = entry;
+  T.sp += valid ? 1 : 0;
 }
 
 __device__ __forceinline__ uint32_t stack_pop(Trav& T, const uint2* lds, const uint2* ovf) {
@@ -480,7 +496,30 @@ __device__ __forceinline__ void trav_run(const DevScene& s, Trav& T, uint2* lds,
         raw[4 * k + 2] = q[k].z;
         raw[4 * k + 3] = q[k].w;
       }
-      if (__builtin_amdgcn_ballot_w64(T.odd != 0u) == 0ull) {  // wave-uniform: a real branch
+      const bool plain = __builtin_amdgcn_ballot_w64(T.odd != 0u) == 0ull;  // wave-uniform: a real branch
+      if (MS == MS_SHADOW && !RT_SHADOW_SORT && RT_PUSH_BRANCHLESS && plain &&
+          __builtin_amdgcn_ballot_w64(T.sp > RT_LDS_STACK - 3) == 0ull) {
+        // Shadow rays, slot order, no branches: children 3, 2, 1 go to the slot above the top (counted only when they are to be
+        // visited); child 0, or else the top of what was just pushed, is next.  Keys are the plain lower bounds.
+        float lo[4];
+        bool v[4];
+        for (int c = 0; c < 4; c++) {
+          if (STATS && raw[24 + c] != RT_FREF_NONE) cnt.node_visits++;
+          v[c] = box_test_f32(T, raw, c, 0.f, raw[24 + c], lo[c]);
+        }
+        for (int c = 3; c > 0; c--) {
+          uint32_t* slot = reinterpret_cast<uint32_t*>(&lds[T.sp * 64]);
+          slot[0] = raw[24 + c];
+          slot[1] = __float_as_uint(lo[c]);
+          T.sp += v[c] ? 1 : 0;
+        }
+        const uint32_t top = v[1] ? raw[25] : (v[2] ? raw[26] : (v[3] ? raw[27] : RT_FREF_NONE));
+        T.sp -= (!v[0] & (v[1] | v[2] | v[3])) ? 1 : 0;
+        T.cur = v[0] ? raw[24] : top;
+        if (T.cur == RT_FREF_NONE) T.cur = stack_pop(T, lds, ovf);
+        continue;
+      }
+      if (plain) {
         const float floorv = all_t ? -INFINITY : 0.f;
         for (int c = 0; c < 4; c++) {
           uint32_t ref = raw[24 + c];
@@ -510,13 +549,28 @@ __device__ __forceinline__ void trav_run(const DevScene& s, Trav& T, uint2* lds,
         RT_CSWAP(1, 3)
         RT_CSWAP(1, 2)
 #undef RT_CSWAP
-        if (entry_key(ent[0]) < RT_KEY_NONE) {
+        if (RT_PUSH_BRANCHLESS && __builtin_amdgcn_ballot_w64(T.sp > RT_LDS_STACK - 3) == 0ull) {
+          for (int c = 3; c > 0; c--) stack_push_if(T, lds, ent[c], entry_key(ent[c]) < RT_KEY_NONE);  // farthest deepest
+          T.cur = entry_key(ent[0]) < RT_KEY_NONE ? entry_ref(ent[0]) : RT_FREF_NONE;
+          if (T.cur == RT_FREF_NONE) T.cur = stack_pop(T, lds, ovf);
+        } else if (entry_key(ent[0]) < RT_KEY_NONE) {
           for (int c = 3; c > 0; c--)  // farthest deepest
             if (entry_key(ent[c]) < RT_KEY_NONE) stack_push(T, lds, ovf, ent[c]);
           T.cur = entry_ref(ent[0]);
         } else {
           T.cur = stack_pop(T, lds, ovf);
         }
+      } else if (RT_PUSH_BRANCHLESS && __builtin_amdgcn_ballot_w64(T.sp > RT_LDS_STACK - 3) == 0ull) {
+        // slot order, without branches: children 3, 2, 1 are pushed; child 0, or else the top of what was just pushed, is next
+        const bool v0 = entry_key(ent[0]) < RT_KEY_NONE, v1 = entry_key(ent[1]) < RT_KEY_NONE, v2 = entry_key(ent[2]) < RT_KEY_NONE,
+                   v3 = entry_key(ent[3]) < RT_KEY_NONE;
+        stack_push_if(T, lds, ent[3], v3);
+        stack_push_if(T, lds, ent[2], v2);
+        stack_push_if(T, lds, ent[1], v1);
+        const uint32_t top = v1 ? entry_ref(ent[1]) : (v2 ? entry_ref(ent[2]) : (v3 ? entry_ref(ent[3]) : RT_FREF_NONE));
+        T.sp -= (!v0 & (v1 | v2 | v3)) ? 1 : 0;
+        T.cur = v0 ? entry_ref(ent[0]) : top;
+        if (T.cur == RT_FREF_NONE) T.cur = stack_pop(T, lds, ovf);
       } else {
         // slot order: the first child to visit becomes current, the others are pushed
         double nxt = pack_entry(RT_FREF_NONE, RT_KEY_NONE);
