@@ -443,8 +443,18 @@ __device__ __forceinline__ bool trav_busy(const Trav& T) { return T.cur != RT_FR
 // fewer than min_active lanes of the wavefront are still traversing, so that the idle ones can fetch their next ray.
 // CSG = false: the kernel is only ever launched on scenes without CSG objects and carries no code for them (their
 // evaluation, csg_survivors, costs the traversal loops registers: the 4K frame of a CSG-free scene 39.7 -> 36.6 ms).
+// top (RT_LDS_NODES > 0, the streamed trace kernels): the first RT_LDS_NODES nodes of the tree — its top levels, numbered
+// breadth-first by fold_nodes — as the workgroup's copy in LDS; a node step on one of them reads that copy.
+// EXPERIMENT, off by default.  Measured (4K frame / one-dragon 800x800 frame): 35.07 / 3.17 ms without, 35.59 / 3.22 ms with
+// 5 nodes (two levels), 35.45 / 3.23 ms with 16 (2 KB more LDS per wavefront: exactly the 160 KB of a CU at 16 wavefronts).
+// The top nodes are the hottest lines of the vector L1 already; the copy saves a fraction of a short latency and pays a
+// divergent branch in every node step.
+#ifndef RT_LDS_NODES
+#define RT_LDS_NODES 0
+#endif
 template <bool STATS, int MS = MS_ALL, bool CSG = true>
-__device__ __forceinline__ void trav_run(const DevScene& s, Trav& T, uint2* lds, uint2* ovf, Counters& cnt, uint32_t min_active = 0) {
+__device__ __forceinline__ void trav_run(const DevScene& s, Trav& T, uint2* lds, uint2* ovf, Counters& cnt, uint32_t min_active = 0,
+                                         const uint4* top = nullptr) {
   while (trav_busy(T)) {
     if (min_active && (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(true)) < min_active) break;
     unsigned long long tc0 = (STATS && min_active) ? (unsigned long long)clock64() : 0ull;
@@ -488,7 +498,15 @@ __device__ __forceinline__ void trav_run(const DevScene& s, Trav& T, uint2* lds,
       const uint4* np = reinterpret_cast<const uint4*>(s.nodes + (T.cur & RT_FREF_INDEX_MASK));
       constexpr int NQ = 7;
       uint4 q[NQ];
-      for (int k = 0; k < NQ; k++) q[k] = np[k];
+#if RT_LDS_NODES
+      const uint32_t ni = T.cur & RT_FREF_INDEX_MASK;
+      if (top && ni < (uint32_t)RT_LDS_NODES) {
+        for (int k = 0; k < NQ; k++) q[k] = top[ni * 8u + k];
+      } else
+#endif
+      {
+        for (int k = 0; k < NQ; k++) q[k] = np[k];
+      }
       uint32_t raw[NQ * 4];
       for (int k = 0; k < NQ; k++) {
         raw[4 * k] = q[k].x;

@@ -310,6 +310,19 @@ __device__ __forceinline__ void flag_sample(const Ws& w, uint32_t root) {
 #define RT_REFILL_BELOW 24
 #endif
 
+// EXPERIMENT (RT_LDS_NODES > 0): the workgroup's copy of the tree's first nodes in LDS (rt_scene_create pads the node table to
+// at least that many).
+#if RT_LDS_NODES
+#define RT_LOAD_TOP_NODES(s)                                                                                       \
+  __shared__ uint4 lds_top_nodes[RT_LDS_NODES * 8];                                                                  \
+  for (uint32_t i_ = threadIdx.x & 63u; i_ < RT_LDS_NODES * 8u; i_ += 64u)                                           \
+    lds_top_nodes[i_] = reinterpret_cast<const uint4*>(s.nodes)[i_];                                                 \
+  __syncthreads();                                                                                                 \
+  const uint4* lds_top = lds_top_nodes;
+#else
+#define RT_LOAD_TOP_NODES(s) const uint4* lds_top = nullptr;
+#endif
+
 #ifndef RT_CLOSEST_WAVES
 #define RT_CLOSEST_WAVES 3  // the closest-hit kernel also carries the container walk and CSG: 168 VGPRs, no spills in its loops (measured best)
 #endif
@@ -319,6 +332,7 @@ __global__ __launch_bounds__(64, RT_CLOSEST_WAVES) void trace_closest_kernel(Dev
                                                                           uint32_t* overflow_flag) {
   __shared__ uint2 lds_stack[RT_LDS_STACK * 64];
   uint2* lds = lds_stack + (threadIdx.x & 63u);
+  RT_LOAD_TOP_NODES(s)
   uint2 ovf[RT_OVF_STACK];
   Counters cnt = {};
   const unsigned long long clk0 = STATS ? (unsigned long long)clock64() : 0ull;
@@ -366,7 +380,7 @@ __global__ __launch_bounds__(64, RT_CLOSEST_WAVES) void trace_closest_kernel(Dev
     }
     // ---- traverse; once the queue is dry there is nothing to refill with, so run to completion ----
     uint32_t min_active = __builtin_amdgcn_ballot_w64(exhausted) != 0ull ? 0u : (uint32_t)RT_REFILL_BELOW;
-    fast::trav_run<STATS, fast::MS_CLOSEST_CONTAINERS, CSG>(s, T, lds, ovf, cnt, min_active);
+    fast::trav_run<STATS, fast::MS_CLOSEST_CONTAINERS, CSG>(s, T, lds, ovf, cnt, min_active, lds_top);
     // ---- lanes whose traversal is complete ----
     if (my != RT_NONE && !fast::trav_busy(T)) {
       if (T.mode == fast::M_CLOSEST) {
@@ -689,6 +703,7 @@ __global__ __launch_bounds__(64, RT_TRACE_WAVES) void trace_shadow_kernel(DevSce
                                                                          unsigned long long* stats, uint32_t* overflow_flag) {
   __shared__ uint2 lds_stack[RT_LDS_STACK * 64];
   uint2* lds = lds_stack + (threadIdx.x & 63u);
+  RT_LOAD_TOP_NODES(s)
   uint2 ovf[RT_OVF_STACK];
   Counters cnt = {};
   const unsigned long long clk0 = STATS ? (unsigned long long)clock64() : 0ull;
@@ -733,7 +748,7 @@ __global__ __launch_bounds__(64, RT_TRACE_WAVES) void trace_shadow_kernel(DevSce
       continue;
     }
     uint32_t min_active = __builtin_amdgcn_ballot_w64(exhausted) != 0ull ? 0u : (uint32_t)RT_REFILL_BELOW;
-    fast::trav_run<STATS, fast::MS_SHADOW, CSG>(s, T, lds, ovf, cnt, min_active);
+    fast::trav_run<STATS, fast::MS_SHADOW, CSG>(s, T, lds, ovf, cnt, min_active, lds_top);
     if (my != RT_NONE && !fast::trav_busy(T)) {
       st_stream(&w.shadow[(size_t)light * cap + my], T.a);
       my = RT_NONE;

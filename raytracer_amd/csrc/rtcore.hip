@@ -847,8 +847,11 @@ void fold_nodes(FastLayout& L) {
   std::vector<Todo> todo{{0u, 0u, 0u}};
   L.stack_need = 0;
   while (!todo.empty()) {
-    Todo t = todo.back();
-    todo.pop_back();
+    // (RT_LDS_NODES: the first nodes are numbered breadth-first — the top levels of the tree —, the rest depth-first)
+    const bool breadth_first = L.nodes.size() < (size_t)RT_LDS_NODES;
+    Todo t = breadth_first ? todo.front() : todo.back();
+    if (breadth_first) todo.erase(todo.begin());
+    else todo.pop_back();
     std::vector<Slot> slots;
     auto add_children = [&](uint32_t b) {
       for (int c = 0; c < 2; c++) {
@@ -1811,6 +1814,7 @@ int rt_scene_create(const rt_scene_desc* d, rt_scene** out) {
     std::vector<T> _v((ptr), (ptr) + (size_t)(n));     \
     UP(_v, field);                                     \
   } while (0)
+  if (L.nodes.size() < (size_t)RT_LDS_NODES) L.nodes.resize(RT_LDS_NODES);  // (the trace kernels copy that many to LDS)
   UP(L.nodes, nodes);
   UP(L.leaf_ref, leaf_ref);
   {
