@@ -104,7 +104,7 @@ struct __attribute__((aligned(128))) DevNode {
 #endif
 
 // Triangles are stored in leaf order, RT_TRI_STRIDE doubles each (80 B, 16-B aligned): p1, e1, e2, then the
-// primitive index in the low 32 bits of the tenth slot.
+// primitive index in the low 32 bits of the tenth slot (bit RT_TRI_OPAQUE_BIT: its material is opaque).
 #define RT_TRI_STRIDE 10
 
 // --- reference-order path (rt_reforder.h): one record per child reference of the input tree -------
@@ -124,6 +124,9 @@ struct __attribute__((aligned(16))) DevEntry {
 #define RT_LEAFREC_INLINE 1u   // flags: shape / matrix / y range below are valid (an analytic primitive)
 #define RT_LEAFREC_XFORM 2u    // flags: the primitive has a transformation_inverse (object.rs:432-439)
 #define RT_LEAFREC_CLOSED 4u   // flags: cylinder / cone is closed
+#define RT_LEAFREC_OPAQUE 8u   // flags: the material's transparency is 0: a shadow ray's hit counts 1 without reading the material
+#define RT_TRI_OPAQUE_BIT 32   // the same, bit of a triangle record's tenth slot (the primitive index is its low word)
+#define RT_MAT_OPAQUE 0xFFFFFFFFu  // add_roots' material argument: transparency 0, no table to read
 struct __attribute__((aligned(128))) DevLeafRec {
   uint32_t ref;       // RT_MAKE_REF(kind, index), as in leaf_ref
   uint32_t shape;     // enum rt_shape

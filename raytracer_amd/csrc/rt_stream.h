@@ -762,7 +762,10 @@ __global__ __launch_bounds__(64, RT_TRACE_WAVES) void trace_shadow_kernel(DevSce
 // ---------------------------------------------------------------------------------------------
 // combine: Integrator::shade_hit_at_depth (integrator.rs:199-228) for every node of one level, deepest level first.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void combine_kernel(DevScene s, DevOptions opt, Ws w, uint32_t level) {
+#ifndef RT_COMBINE_WAVES
+#define RT_COMBINE_WAVES 3  // 150 registers, no spills; 4 (128 registers, 17 spilled): 2.55 -> 3.29 ms on the 4K frame
+#endif
+__global__ __launch_bounds__(256, RT_COMBINE_WAVES) void combine_kernel(DevScene s, DevOptions opt, Ws w, uint32_t level) {
   const uint32_t begin = level == 0 ? 0u : w.ctrl->level_end[level - 1], end = w.ctrl->level_end[level];
   const size_t cap = w.cap_nodes;
   for (uint32_t node = begin + blockIdx.x * blockDim.x + threadIdx.x; node < end; node += gridDim.x * blockDim.x) {

@@ -1785,6 +1785,7 @@ int rt_scene_create(const rt_scene_desc* d, rt_scene** out) {
       tn[6 + k] = d->tri_n3[src * 3 + k];
     }
     uint64_t bits = i;
+    if (d->material[(size_t)d->prim_material[i] * RT_MAT_STRIDE + RT_MAT_TRANSPARENCY] == 0.) bits |= 1ull << RT_TRI_OPAQUE_BIT;
     std::memcpy(ti + 9, &bits, sizeof(bits));
   }
   std::vector<double> quadric((size_t)d->n_quadrics * 2);
@@ -1830,6 +1831,7 @@ int rt_scene_create(const rt_scene_desc* d, rt_scene** out) {
       r.shape = sh;
       r.material = d->prim_material[p];
       r.flags = RT_LEAFREC_INLINE;
+      if (d->material[(size_t)r.material * RT_MAT_STRIDE + RT_MAT_TRANSPARENCY] == 0.) r.flags |= RT_LEAFREC_OPAQUE;
       if (d->prim_xform[p] != RT_NONE) {
         r.flags |= RT_LEAFREC_XFORM;
         std::memcpy(r.inv, d->xform_inv + (size_t)d->prim_xform[p] * 16, sizeof(r.inv));
