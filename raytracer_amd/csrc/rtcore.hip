@@ -597,8 +597,10 @@ struct FastLayout {
   std::vector<uint32_t> prim_tri;  // triangle primitives: slot in the device triangle tables (leaf order), else RT_NONE
   uint32_t n_dev_tris = 0;
   uint32_t depth = 0;
-  uint32_t leaf_tris = 4;      // all-triangle subtrees of at most this many triangles are one leaf (<= 2: the reference's
-                               // leaves; 4 measured best: dragons 4K 54.5 -> 53.0 ms, dragon 800x800 4.47 -> 4.15 ms)
+  uint32_t leaf_tris = 2;      // all-triangle subtrees of at most this many triangles are one leaf (<= 2: the reference's own
+                               // leaves).  4 was best while a node step cost 30 instructions per box (r01: dragons 4K 54.5 ->
+                               // 53.0 ms); with the f32 slab test 2 is: 34.6 -> 34.0 ms (3: 34.2, 6: 35.4, 8: 36.5; the one-dragon
+                               // 800x800 frame 3.20 -> 3.27 ms).  RT_LEAF_TRIS in the environment overrides.
   std::string error;
 };
 
