@@ -1,15 +1,17 @@
-// rt_fast.h — the per-pixel render core as gfx950 device code (the path that ships and is benchmarked).
+// rt_fast.h — BVH traversal (fast::trav_run, what every production kernel traces rays with) and the per-pixel render core
+// as ONE kernel (the single-kernel pipeline: comparison path, overflow fallback of the streamed pipeline, rt_stream.h).
 //
-// One wavefront (64 lanes) renders one 8x8 pixel tile; each lane owns one pixel and runs the whole
+// Single kernel: one wavefront (64 lanes) renders one 8x8 pixel tile; each lane owns one pixel and runs the whole
 // Renderer::color_at_pixel (src/render/renderer.rs:50-66) for it.
 //
 //  * The reflect/refract recursion of Integrator::shade_hit_at_depth (src/shading/integrator.rs:199-228) is a
 //    per-lane state machine over an explicit frame stack (post-order, so every sum is formed in the reference's
 //    order).  EVERY ray of the machine — primary, reflected, refracted, shadow, and the refractive-container walk —
 //    goes through ONE traversal loop, so lanes that are at different points of the recursion still traverse together.
-//  * Traversal is a while-while loop over 128-B binary nodes (both child boxes per fetch), near child first, with the
-//    per-lane stack in LDS (RT_LDS_STACK entries, deeper entries spill to scratch).  The far child is pushed with its
-//    entry time rounded down to f32 and dropped at pop time once the closest hit is nearer.
+//  * Traversal is a while-while loop over 128-B four-wide nodes (the boxes of up to four children per fetch, f32, rounded
+//    outward), tested conservatively in f32 (box_test_f32), nearest child first (shadow rays: slot order), with the
+//    per-lane stack in LDS (RT_LDS_STACK entries, deeper entries spill to scratch).  The other children are pushed with a
+//    lower bound of their entry time and dropped at pop time once the closest hit is nearer.
 //  * What makes a different visiting order legal: the closest hit of the reference is "smallest t, first visited wins
 //    ties" (intersection.rs:65-77, strict <).  The visit order of ObjectGroup::intersect_iter (group.rs:171-201) is a
 //    fixed pre-order of the tree, so "first visited" = smallest prim_rank, which is what ties are resolved with here.
