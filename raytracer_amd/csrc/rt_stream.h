@@ -71,6 +71,7 @@ struct Ws {  // workspace of one batch (device pointers; owned by rt_scene)
   double* node_f;        // [NF_COUNT][cap_nodes]
   uint32_t* node_u;      // [NU_COUNT][cap_nodes]
   double* shadow;        // [n_lights][cap_nodes] accumulated shadow intensity (IntersectionCollector, intersection.rs:78-87)
+  uint8_t* node_lit;     // [cap_nodes] bit l: light l is on the node's side of its surface, i.e. its shadow ray is traced (lit_bits)
   double* sample_rgb;    // [n_samples][3]
   uint8_t* sample_flag;  // [n_samples] 1: re-render this sample in the fallback kernel
   uint32_t* tile_xy;     // [n_samples / 64] Batch::tile_xy
@@ -196,8 +197,129 @@ template <class T> __device__ __forceinline__ void st_stream(T* p, T v) { __buil
 template <class T> __device__ __forceinline__ T ld_stream(const T* p) { return *p; }
 template <class T> __device__ __forceinline__ void st_stream(T* p, T v) { *p = v; }
 #endif
+// Makes [c.next, c.end) non-empty — the next items of this wavefront's XCD's share, or of the next XCD's that has any left —
+// and names the XCD they belong to; false when nothing is left.  Called by all 64 lanes.
+__device__ __forceinline__ bool xcd_range(uint32_t* counters, uint32_t n_items, XcdCursor& c, uint32_t& xx_out) {
+#ifdef RT_HOST_EMU
+  const bool first = true;  // (a wavefront is one lane)
+#else
+  const bool first = (threadIdx.x & 63u) == 0u;
+#endif
+  while (c.victim < 8u) {
+    const uint32_t xx = (c.xcd + c.victim) & 7u;
+    xx_out = xx;
+    if (c.next != c.end) return true;
+    const uint32_t share = xcd_share(n_items, xx);
+    if (share == 0u || ((c.done >> xx) & 1u)) {
+      c.victim++;
+      continue;
+    }
+    uint32_t q = 0;
+    if (first) q = atomicAdd(&counters[xx], c.grab);
+    q = __builtin_amdgcn_readfirstlane(q);
+    if (q >= share) {  // used up (see xcd_take)
+      uint32_t seen = __hip_atomic_load(&counters[8], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (first && !((seen >> xx) & 1u)) atomicOr(&counters[8], 1u << xx);
+      c.done |= __builtin_amdgcn_readfirstlane(seen) | (1u << xx);
+      c.victim++;
+      continue;
+    }
+    c.next = q;
+    c.end = min(q + c.grab, share);
+    const uint32_t left = share - c.end;
+    c.grab = min(max((left / max(gridDim.x / 4u, 1u)) & ~63u, 64u), (uint32_t)RT_XCD_GRAB);
+    return true;
+  }
+  return false;
+}
+
+// trace_shadow_kernel's items are (light, node) pairs, light-major; 28 % of the bench frame's have the light behind the
+// surface and get no ray.  Handing those to lanes would leave the lanes idle until the next refill (and the refill is the
+// expensive part of a short ray), so a wavefront looks at its items 64 at a time — one byte of node_lit each —, writes the
+// zero of the unlit ones and hands only the lit ones out: the k-th lane that wants a ray takes the k-th pending item of the
+// window.  All fields wave-uniform.
+struct LitWindow {
+  uint32_t id0;                 // item id of the window's lane 0 (the window's items are consecutive)
+  unsigned long long pending;   // bit i: item id0 + i is lit and not handed out yet
+};
+template <bool STATS>
+__device__ __forceinline__ uint32_t lit_take(const Ws& w, uint32_t* counters, uint32_t n_items, uint32_t n_nodes, uint32_t node0,
+                                             XcdCursor& c, LitWindow& win, bool want, Counters& cnt) {
+#ifdef RT_HOST_EMU
+  const uint32_t lane = 0u, wave = 1u;  // (a wavefront is one lane)
+#else
+  const uint32_t lane = threadIdx.x & 63u, wave = 64u;
+#endif
+  uint32_t id = RT_NONE;
+  for (;;) {
+    const bool wq = want && id == RT_NONE;
+    const unsigned long long wm = __builtin_amdgcn_ballot_w64(wq);
+    if (wm == 0ull) break;
+    if (win.pending == 0ull) {  // the next window: up to 64 consecutive items of the private range
+      uint32_t xx = 0;
+      if (!xcd_range(counters, n_items, c, xx)) break;
+      const uint32_t q = c.next, n_win = min(wave, min(c.end - q, RT_XCD_CHUNK - q % RT_XCD_CHUNK));
+      win.id0 = ((q / RT_XCD_CHUNK) * 8u + xx) * RT_XCD_CHUNK + q % RT_XCD_CHUNK;
+      c.next += n_win;
+      bool lit = false;
+      if (lane < n_win) {
+        const uint32_t item = win.id0 + lane, light = item / n_nodes, node = node0 + (item - light * n_nodes);
+        lit = ((w.node_lit[node] >> light) & 1u) != 0u;
+        if (!lit) {
+          st_stream(&w.shadow[(size_t)light * w.cap_nodes + node], 0.);
+          if (STATS) cnt.shadow_culled++;
+        }
+      }
+      win.pending = __builtin_amdgcn_ballot_w64(lit);
+      continue;
+    }
+#ifdef RT_HOST_EMU  // (a wavefront is one lane)
+    id = win.id0;
+    win.pending = 0ull;
+#else
+    // rank r of this lane's item among the pending ones; a permutation sends every lane's index to slot r (pending) or
+    // behind all pending ones (not pending), so that slot k holds the position of the k-th pending item
+    const uint32_t have = (uint32_t)__builtin_popcountll(win.pending), r = rank_in(win.pending);
+    const bool mine = ((win.pending >> lane) & 1ull) != 0ull;
+    const uint32_t slot = mine ? r : have + (lane - r);
+    const uint32_t pos_of = (uint32_t)__builtin_amdgcn_ds_permute((int)(slot << 2), (int)lane);
+    const uint32_t k = rank_in(wm);
+    const uint32_t pos = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((k & 63u) << 2), (int)pos_of);
+    if (wq && k < have) id = win.id0 + pos;
+    const uint32_t handed = min(have, (uint32_t)__builtin_popcountll(wm));
+    win.pending = __builtin_amdgcn_ballot_w64(mine && r >= handed);
+#endif
+  }
+  return id;
+}
+
 __device__ __forceinline__ uint64_t dbits(double d) { return (uint64_t)__double_as_longlong(d); }
 __device__ __forceinline__ double bitsd(uint64_t u) { return __longlong_as_double((long long)u); }
+
+// Which lights get a shadow ray from a surface point: bit l is clear when light l is BEHIND the surface, where
+// color_of_illuminated_point returns the ambient term without looking at the shadow value (point_light.rs:50-55).  The
+// predicate is the one trace_shadow_kernel's shadow_start applies, dot(normalize(light - over), normal) < 0, decided
+// without the square root and the three divisions whenever dot(light - over, normal) is clear of zero by 1e-9 of its
+// terms' magnitudes (normalising divides the three components by one positive number, each quotient rounded by 2^-53, and
+// the dot product rounds three more times: the sign cannot change beyond ~1e-15 of those magnitudes), and exactly
+// otherwise.  More than RT_LIT_LIGHTS lights: every bit set (shadow_start culls).
+#define RT_LIT_LIGHTS 8u
+__device__ __forceinline__ uint32_t lit_bits(const DevScene& s, d3 over, d3 normal) {
+  if (s.n_lights > RT_LIT_LIGHTS) return 0xFFu;
+  uint32_t bits = 0;
+  for (uint32_t l = 0; l < s.n_lights; l++) {
+    const double* lp = s.light_pos + (size_t)l * 3;
+    d3 vv = sub3(mk3(lp[0], lp[1], lp[2]), over);
+    double tx = vv.x * normal.x, ty = vv.y * normal.y, tz = vv.z * normal.z;
+    double c = tx + ty + tz, bound = 1.0e-9 * (fabs(tx) + fabs(ty) + fabs(tz));
+    bool lit;
+    if (c > bound) lit = true;
+    else if (c < -bound) lit = false;
+    else lit = !(dot3(normalize3(vv), normal) < 0.);
+    bits |= lit ? (1u << l) : 0u;
+  }
+  return bits;
+}
 
 // Pixel of lane-slot p of the tile at position kpos of this part's tile order (the order rt_render_tiles_device packs).
 __device__ __forceinline__ void tile_pixel(const Batch& b, uint32_t kpos, uint32_t p, uint32_t& px, uint32_t& py) {
@@ -528,6 +650,7 @@ __device__ __forceinline__ void shade_hit(const DevScene& s, const rt_camera& ca
     for (int k = 0; k < 3; k++) nf[(NF_REFL + k) * cap] = 0.;
   if (out.want_refract)
     for (int k = 0; k < 3; k++) nf[(NF_REFR + k) * cap] = 0.;
+  w.node_lit[node] = (uint8_t)lit_bits(s, g.over, g.normal);
   uint32_t* nu = w.node_u + node;
   nu[NU_PRIM * cap] = prim | (out.want_reflect ? RT_NODE_REFLECTED : 0u) | (out.want_refract ? RT_NODE_REFRACTED : 0u);
   nu[NU_PARENT * cap] = parent;
@@ -720,10 +843,11 @@ __global__ __launch_bounds__(64, RT_TRACE_WAVES) void trace_shadow_kernel(DevSce
   uint32_t my = RT_NONE, light = 0;  // the node this lane is working on, and the light of its current ray
   bool exhausted = false;
   XcdCursor cursor = xcd_cursor(n_items);
+  LitWindow window = {0u, 0ull};
   for (;;) {
     bool want = my == RT_NONE && !exhausted;
     if (__builtin_amdgcn_ballot_w64(want) != 0ull) {
-      uint32_t id = xcd_take(w.ctrl->shadow_fetch[level], n_items, cursor, want);
+      uint32_t id = lit_take<STATS>(w, w.ctrl->shadow_fetch[level], n_items, n_nodes, node0, cursor, window, want, cnt);
       if (want) {
         if (id != RT_NONE) {
           light = id / n_nodes;

@@ -1123,6 +1123,7 @@ size_t carve_workspace(stream::Ws* w, char* base, uint64_t n, uint32_t ratio, ui
   size_t o_nf = take((size_t)cap_nodes * stream::NF_COUNT * 8);
   size_t o_nu = take((size_t)cap_nodes * stream::NU_COUNT * 4);
   size_t o_shadow = take((size_t)cap_nodes * std::max<uint32_t>(n_lights, 1u) * 8);
+  size_t o_lit = take((size_t)cap_nodes);
   size_t o_rgb = take((size_t)n * 24);
   size_t o_flag = take((size_t)n);
   size_t o_tiles = take((size_t)n / 64 * 4 + 4);
@@ -1137,6 +1138,7 @@ size_t carve_workspace(stream::Ws* w, char* base, uint64_t n, uint32_t ratio, ui
     w->node_f = (double*)(base + o_nf);
     w->node_u = (uint32_t*)(base + o_nu);
     w->shadow = (double*)(base + o_shadow);
+    w->node_lit = (uint8_t*)(base + o_lit);
     w->sample_rgb = (double*)(base + o_rgb);
     w->sample_flag = (uint8_t*)(base + o_flag);
     w->tile_xy = (uint32_t*)(base + o_tiles);
