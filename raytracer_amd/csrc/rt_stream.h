@@ -446,9 +446,14 @@ __device__ __forceinline__ void flag_sample(const Ws& w, uint32_t root) {
 #endif
 
 #ifndef RT_CLOSEST_WAVES
-#define RT_CLOSEST_WAVES 3  // the closest-hit kernel also carries the container walk and CSG: 168 VGPRs, no spills in its loops (measured best)
+#define RT_CLOSEST_WAVES 3  // the closest-hit kernel also carries the container walk: 150 VGPRs (level 0) / 143 (deeper levels), no spills;
+                            // 4 waves for the deeper levels (128 VGPRs, 12 spilled): 11.50 -> 11.63 ms.  Container walks as a kernel of
+                            // their own (glass hits listed, walked after the retrace; closest-hit kernel 139 / 125 VGPRs, 4 waves for the
+                            // deeper levels; the walk pruned by the second-innermost container found so far) was SLOWER: closest hits
+                            // 10.7 ms + walks 1.85 ms against 11.75 ms together — a walk is short (few boxes lie behind a ray's origin),
+                            // pruning changes nothing, and what it costs is a ray's set-up, which the same lane doing both pays once
 #endif
-template <bool CAMERA, bool STATS, bool CSG>
+template <bool CAMERA, bool STATS, bool CSG, bool FIRST>
 __global__ __launch_bounds__(64, RT_CLOSEST_WAVES) void trace_closest_kernel(DevScene s, rt_camera cam, DevOptions opt, Ws w, Batch b,
                                                                           uint32_t level, unsigned long long* stats,
                                                                           uint32_t* overflow_flag) {
@@ -458,7 +463,9 @@ __global__ __launch_bounds__(64, RT_CLOSEST_WAVES) void trace_closest_kernel(Dev
   uint2 ovf[RT_OVF_STACK];
   Counters cnt = {};
   const unsigned long long clk0 = STATS ? (unsigned long long)clock64() : 0ull;
-  const uint32_t n_rays = level == 0 ? b.n_samples : w.ctrl->n_rays[level];
+  // FIRST: level 0, whose rays are generated here (the camera's, or the batch's given ones); the deeper levels read their
+  // queue and carry no camera code (162 VGPRs for one kernel doing both; 150 / 143 apart: 11.74 -> 11.50 ms on the 4K frame)
+  const uint32_t n_rays = FIRST ? b.n_samples : w.ctrl->n_rays[level];
   const double* __restrict__ queue = w.rays[level & 1];
   fast::Trav T;
   T.cur = RT_FREF_NONE;
@@ -478,14 +485,14 @@ __global__ __launch_bounds__(64, RT_CLOSEST_WAVES) void trace_closest_kernel(Dev
         if (id != RT_NONE) {
           d3 o, d;
           bool ok = true;
-          if (level == 0) {
+          if (FIRST) {
             ok = first_ray<CAMERA>(cam, opt, b, id, o, d);
           } else {
             uint32_t parent, root;
             load_ray(queue, id, o, d, parent, root);
           }
           if (ok) {
-            if (STATS && level == 0) cnt.rays_primary++;
+            if (STATS && FIRST) cnt.rays_primary++;
             my = id;
             fast::trav_start(T, o, d, fast::M_CLOSEST, INFINITY);
           } else {

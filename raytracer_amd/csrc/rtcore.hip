@@ -1301,12 +1301,17 @@ int run_stream_batch(const rt_scene* sc, const stream::Ws& w, const rt_camera& c
     {
       TimedLaunch t(sc, st, TC_TRACE_CLOSEST);
       // (the kernels without counters come in two builds: with and without the code for CSG objects)
-      if (STATS || sc->has_csg)
-        hipLaunchKernelGGL((stream::trace_closest_kernel<CAMERA, STATS, true>), dim3(closest_grid), dim3(64), 0, st, sc->dev, cam, dopt, w, b,
-                           level, sc->d_stats, sc->d_overflow);
-      else
-        hipLaunchKernelGGL((stream::trace_closest_kernel<CAMERA, false, false>), dim3(closest_grid), dim3(64), 0, st, sc->dev, cam, dopt, w, b,
-                           level, sc->d_stats, sc->d_overflow);
+#define RT_LAUNCH_CLOSEST(ST, CSG, FIRST)                                                                                                \
+  hipLaunchKernelGGL((stream::trace_closest_kernel<CAMERA, ST, CSG, FIRST>), dim3(closest_grid), dim3(64), 0, st, sc->dev, cam, dopt, w, b, \
+                     level, sc->d_stats, sc->d_overflow)
+      if (STATS || sc->has_csg) {
+        if (level == 0) RT_LAUNCH_CLOSEST(STATS, true, true);
+        else RT_LAUNCH_CLOSEST(STATS, true, false);
+      } else {
+        if (level == 0) RT_LAUNCH_CLOSEST(false, false, true);
+        else RT_LAUNCH_CLOSEST(false, false, false);
+      }
+#undef RT_LAUNCH_CLOSEST
     }
     {
       TimedLaunch t(sc, st, TC_RETRACE);
