@@ -128,11 +128,30 @@ struct XcdCursor {
   uint32_t xcd, victim, next, end;  // [next, end): items of XCD (xcd + victim) & 7's share this wavefront has taken
   uint32_t grab;                    // items per atomic: 64 .. RT_XCD_GRAB, so that every wavefront still gets several turns
   uint32_t done;                    // bit x: XCD x's share is known to be used up
+  uint32_t lanes;                   // lanes_in_use: the smallest grab
 };
-__device__ __forceinline__ XcdCursor xcd_cursor(uint32_t n_items) {
-  uint32_t grab = 64u;
-  while (grab < RT_XCD_GRAB && (unsigned long long)grab * gridDim.x * 8u < n_items) grab <<= 1;
-  return XcdCursor{blockIdx.x & 7u, 0u, 0u, 0u, grab, 0u};
+__device__ __forceinline__ XcdCursor xcd_cursor(uint32_t n_items, uint32_t lanes = 64u) {
+  uint32_t grab = lanes;
+  while (grab >= 64u && grab < RT_XCD_GRAB && (unsigned long long)grab * gridDim.x * 8u < n_items) grab <<= 1;
+  return XcdCursor{blockIdx.x & 7u, 0u, 0u, 0u, grab, 0u, lanes};
+}
+
+// A launch with few items (the deep levels of a frame, a small image, one GPU's part of a frame split eight ways) is bound by
+// its slowest wavefront, and a wavefront's time grows with the number of DIFFERENT rays it interleaves: such a launch hands
+// each wavefront fewer rays — lanes at and above the returned number never take any — so that all of the GPU's wavefronts
+// share the work (64 items per wavefront would leave most of them without).
+#ifndef RT_THIN_WAVES
+#define RT_THIN_WAVES 1
+#endif
+__device__ __forceinline__ uint32_t lanes_in_use(uint32_t n_items) {
+#ifdef RT_HOST_EMU
+  return 64u;
+#else
+  if (!RT_THIN_WAVES) return 64u;
+  uint32_t per_wave = (n_items + gridDim.x - 1u) / gridDim.x, lanes = 8u;
+  while (lanes < 64u && lanes < per_wave) lanes <<= 1;
+  return lanes;
+#endif
 }
 
 // Number of items in XCD xx's share: q in [0, share) <-> item ((q / CHUNK) * 8 + xx) * CHUNK + q % CHUNK < n_items.
@@ -176,7 +195,7 @@ __device__ __forceinline__ uint32_t xcd_take(uint32_t* counters, uint32_t n_item
       // guided: the nearer the share's end, the smaller the next grab, so that no wavefront sits on a long private range
       // while the others have run dry
       uint32_t left = share - c.end;
-      c.grab = min(max((left / max(gridDim.x / 4u, 1u)) & ~63u, 64u), (uint32_t)RT_XCD_GRAB);
+      c.grab = min(max((left / max(gridDim.x / 4u, 1u)) & ~63u, c.lanes), (uint32_t)RT_XCD_GRAB);
     }
     uint32_t avail = c.end - c.next, r = rank_in(m);
     if (w && r < avail) {
@@ -227,7 +246,7 @@ __device__ __forceinline__ bool xcd_range(uint32_t* counters, uint32_t n_items, 
     c.next = q;
     c.end = min(q + c.grab, share);
     const uint32_t left = share - c.end;
-    c.grab = min(max((left / max(gridDim.x / 4u, 1u)) & ~63u, 64u), (uint32_t)RT_XCD_GRAB);
+    c.grab = min(max((left / max(gridDim.x / 4u, 1u)) & ~63u, c.lanes), (uint32_t)RT_XCD_GRAB);
     return true;
   }
   return false;
@@ -474,8 +493,9 @@ __global__ __launch_bounds__(64, RT_CLOSEST_WAVES) void trace_closest_kernel(Dev
   T.limit = 0.;
   uint32_t my = RT_NONE;  // the ray this lane is working on
   double ht = 0., hu = 0., hv = 0.;  // the hit, kept across the container walk
-  bool exhausted = false;
-  XcdCursor cursor = xcd_cursor(n_rays);
+  const uint32_t lanes = lanes_in_use(n_rays);
+  bool exhausted = (threadIdx.x & 63u) >= lanes;
+  XcdCursor cursor = xcd_cursor(n_rays, lanes);
   for (;;) {
     // ---- idle lanes take the next rays of the level ----
     bool want = my == RT_NONE && !exhausted;
@@ -508,7 +528,7 @@ __global__ __launch_bounds__(64, RT_CLOSEST_WAVES) void trace_closest_kernel(Dev
       continue;
     }
     // ---- traverse; once the queue is dry there is nothing to refill with, so run to completion ----
-    uint32_t min_active = __builtin_amdgcn_ballot_w64(exhausted) != 0ull ? 0u : (uint32_t)RT_REFILL_BELOW;
+    uint32_t min_active = __builtin_amdgcn_ballot_w64(exhausted && (threadIdx.x & 63u) < lanes) != 0ull ? 0u : (uint32_t)RT_REFILL_BELOW * lanes / 64u;
     fast::trav_run<STATS, fast::MS_CLOSEST_CONTAINERS, CSG>(s, T, lds, ovf, cnt, min_active, lds_top);
     // ---- lanes whose traversal is complete ----
     if (my != RT_NONE && !fast::trav_busy(T)) {
@@ -848,8 +868,9 @@ __global__ __launch_bounds__(64, RT_TRACE_WAVES) void trace_shadow_kernel(DevSce
   T.limit = 0.;
   T.a = 0.;
   uint32_t my = RT_NONE, light = 0;  // the node this lane is working on, and the light of its current ray
-  bool exhausted = false;
-  XcdCursor cursor = xcd_cursor(n_items);
+  const uint32_t lanes = lanes_in_use(n_items);
+  bool exhausted = (threadIdx.x & 63u) >= lanes;
+  XcdCursor cursor = xcd_cursor(n_items, lanes);
   LitWindow window = {0u, 0ull};
   for (;;) {
     bool want = my == RT_NONE && !exhausted;
@@ -878,7 +899,7 @@ __global__ __launch_bounds__(64, RT_TRACE_WAVES) void trace_shadow_kernel(DevSce
       if (__builtin_amdgcn_ballot_w64(!exhausted) == 0ull) break;
       continue;
     }
-    uint32_t min_active = __builtin_amdgcn_ballot_w64(exhausted) != 0ull ? 0u : (uint32_t)RT_REFILL_BELOW;
+    uint32_t min_active = __builtin_amdgcn_ballot_w64(exhausted && (threadIdx.x & 63u) < lanes) != 0ull ? 0u : (uint32_t)RT_REFILL_BELOW * lanes / 64u;
     fast::trav_run<STATS, fast::MS_SHADOW, CSG>(s, T, lds, ovf, cnt, min_active, lds_top);
     if (my != RT_NONE && !fast::trav_busy(T)) {
       st_stream(&w.shadow[(size_t)light * cap + my], T.a);
