@@ -263,7 +263,7 @@ struct LitWindow {
 };
 template <bool STATS>
 __device__ __forceinline__ uint32_t lit_take(const Ws& w, uint32_t* counters, uint32_t n_items, uint32_t n_nodes, uint32_t node0,
-                                             XcdCursor& c, LitWindow& win, bool want, Counters& cnt) {
+                                             bool all_lit, XcdCursor& c, LitWindow& win, bool want, Counters& cnt) {
 #ifdef RT_HOST_EMU
   const uint32_t lane = 0u, wave = 1u;  // (a wavefront is one lane)
 #else
@@ -283,7 +283,7 @@ __device__ __forceinline__ uint32_t lit_take(const Ws& w, uint32_t* counters, ui
       bool lit = false;
       if (lane < n_win) {
         const uint32_t item = win.id0 + lane, light = item / n_nodes, node = node0 + (item - light * n_nodes);
-        lit = ((w.node_lit[node] >> light) & 1u) != 0u;
+        lit = all_lit || ((w.node_lit[node] >> light) & 1u) != 0u;  // (all_lit: more lights than node_lit has bits, lit_bits)
         if (!lit) {
           st_stream(&w.shadow[(size_t)light * w.cap_nodes + node], 0.);
           if (STATS) cnt.shadow_culled++;
@@ -875,7 +875,7 @@ __global__ __launch_bounds__(64, RT_TRACE_WAVES) void trace_shadow_kernel(DevSce
   for (;;) {
     bool want = my == RT_NONE && !exhausted;
     if (__builtin_amdgcn_ballot_w64(want) != 0ull) {
-      uint32_t id = lit_take<STATS>(w, w.ctrl->shadow_fetch[level], n_items, n_nodes, node0, cursor, window, want, cnt);
+      uint32_t id = lit_take<STATS>(w, w.ctrl->shadow_fetch[level], n_items, n_nodes, node0, s.n_lights > RT_LIT_LIGHTS, cursor, window, want, cnt);
       if (want) {
         if (id != RT_NONE) {
           light = id / n_nodes;

@@ -6,6 +6,7 @@ Bar (north star): <= 1 LSB per 8-bit channel on >= 99.9 % of pixels.  Tighter ba
 1e-9 absolute of the oracle (everything except pow() in the specular term is bit-exact by construction) and u8
 identical on >= 99.9 % of pixels."""
 import ctypes as C
+import math
 import os
 
 import numpy as np
@@ -136,6 +137,25 @@ def test_empty_scene_and_no_lights():
     gpu, _ = R.render(sb.flatten(), S.make_camera(16, 16, 1.0, S.view_transformation((0, 0, -5), (0, 0, 0), (0, 1, 0))),
                       S.make_options(1, 4, True))
     assert np.array_equal(gpu, np.zeros((16, 16, 3)))
+
+
+def test_lights_around_the_scene_one_to_ten():
+    """Which (hit, light) pairs get a shadow ray is decided per node by the shade kernel (lit_bits: one bit per light, up to 8;
+    beyond that every pair is handed to the shadow kernel, which culls itself): scenes with 1, 4, 8, 9 and 10 lights placed
+    all around two spheres and a floor, so that every surface point has lights on both of its sides."""
+    for n in (1, 4, 8, 9, 10):
+        sb = default_testing_builder(light=None, extra=[(N.PLANE, S.Material(reflectivity=0.3), translation(0., -1., 0.))])
+        for k in range(n):
+            a = 2. * math.pi * k / n
+            sb.add_light((6. * math.cos(a), 4. * math.sin(3. * a) + 1., 6. * math.sin(a)), (1. / n, 1. / n, 1. / n))
+        cam = S.make_camera(48, 40, 1.0, S.view_transformation((0, 1.5, -5), (0, 0, 0), (0, 1, 0)))
+        opt = S.make_options(supersampling_level=1, max_depth=3, shadow_intensity=True)
+        flat = sb.flatten()
+        gpu, st = R.render(flat, cam, opt)
+        check_against_oracle(flat, cam, opt, gpu=gpu)
+        ref, st_ref = R.render(flat, cam, _ref_order(opt))
+        assert float(np.abs(gpu - ref).max()) < 1e-12
+        assert st["rays_shadow"] + st["rays_shadow_culled"] == st_ref["rays_shadow"] and (n == 1 or st["rays_shadow_culled"] > 0)
 
 
 def test_invalid_arguments_fail_loudly():
