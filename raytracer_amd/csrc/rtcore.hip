@@ -726,13 +726,40 @@ void assign_ranks(const rt_scene_desc* d, std::vector<uint32_t>& rank) {
   }
 }
 
+// A vector that lives on the stack until it outgrows N elements: rt_scene_create walks ~2 groups per triangle, and three
+// heap vectors per group were a third of a scene's creation time.
+template <class T, int N>
+struct SmallVec {
+  T inl[N];
+  std::vector<T> big;
+  size_t n = 0;
+  void push_back(const T& v) {
+    if (n < (size_t)N) {
+      inl[n++] = v;
+      return;
+    }
+    if (n == (size_t)N) big.assign(inl, inl + N);
+    big.push_back(v);
+    n++;
+  }
+  size_t size() const { return n; }
+  bool empty() const { return n == 0; }
+  const T* data() const { return n <= (size_t)N ? inl : big.data(); }
+  const T& operator[](size_t i) const { return data()[i]; }
+};
+typedef SmallVec<uint32_t, 8> RefList;
+typedef SmallVec<FastItem, 8> ItemList;
+
 // Emits the reference(s) for a run of direct primitive/CSG children of one group, tested behind `bb` (the group's box).
 // More than RT_FREF_LEAF_MAX of them become several leaves.
-void make_leaves(const rt_scene_desc* d, FastLayout& L, const std::vector<uint32_t>& refs, const double* bb, std::vector<FastItem>& out) {
+template <class Refs, class Items>
+void make_leaves(const rt_scene_desc* d, FastLayout& L, const Refs& refs, const double* bb, Items& out) {
   bool all_tris = !refs.empty();
-  for (uint32_t r : refs)
+  for (size_t ri = 0; ri < refs.size(); ri++) {
+    const uint32_t r = refs[ri];
     if ((r >> RT_REF_KIND_SHIFT) != RT_REF_PRIM || !is_triangle_prim(d, r & RT_REF_INDEX_MASK) || L.prim_tri[r & RT_REF_INDEX_MASK] != RT_NONE)
       all_tris = false;
+  }
   for (size_t at = 0; at < refs.size(); at += RT_FREF_LEAF_MAX) {
     uint32_t n = (uint32_t)std::min<size_t>(RT_FREF_LEAF_MAX, refs.size() - at);
     FastItem it;
@@ -750,7 +777,8 @@ void make_leaves(const rt_scene_desc* d, FastLayout& L, const std::vector<uint32
 
 // Folds items into binary nodes; returns the reference to the (sub)tree holding all of them.  Synthetic inner
 // references are tested behind `bb` again (a box the ray is already known to hit).
-uint32_t fold_items(FastLayout& L, const std::vector<FastItem>& items, size_t from, const double* bb) {
+template <class Items>
+uint32_t fold_items(FastLayout& L, const Items& items, size_t from, const double* bb) {
   uint32_t id = (uint32_t)L.bin.size();
   L.bin.emplace_back();
   BinNode n;
@@ -805,16 +833,17 @@ uint32_t build_group(const rt_scene_desc* d, FastLayout& L, uint32_t g, uint32_t
       if (one.size() == 1) return one[0].ref;
     }
   }
-  std::vector<uint32_t> direct, groups;
+  RefList direct, groups;
   for (uint32_t i = b; i < e; i++) {
     uint32_t ref = d->child_ref[i];
     if ((ref >> RT_REF_KIND_SHIFT) == RT_REF_NODE) groups.push_back(ref & RT_REF_INDEX_MASK);
     else direct.push_back(ref);
   }
-  std::vector<FastItem> items;
+  ItemList items;
   make_leaves(d, L, direct, bb, items);
   if (groups.empty() && items.size() == 1) return items[0].ref;  // a plain leaf group: no node of its own
-  for (uint32_t c : groups) {
+  for (size_t gi = 0; gi < groups.size(); gi++) {
+    const uint32_t c = groups[gi];
     FastItem it;
     std::memcpy(it.bb, d->node_bbox + (size_t)c * 6, sizeof(it.bb));
     it.ref = build_group(d, L, c, depth + 1);
@@ -848,13 +877,16 @@ void fold_nodes(FastLayout& L) {
   };
   std::vector<Todo> todo{{0u, 0u, 0u}};
   L.stack_need = 0;
+  std::vector<Slot> slots;  // (one allocation for all nodes)
+  slots.reserve(2 * RT_NODE_WIDTH);
+  L.nodes.reserve(L.bin.size() / 2 + 16);
   while (!todo.empty()) {
     // (RT_LDS_NODES: the first nodes are numbered breadth-first — the top levels of the tree —, the rest depth-first)
     const bool breadth_first = L.nodes.size() < (size_t)RT_LDS_NODES;
     Todo t = breadth_first ? todo.front() : todo.back();
     if (breadth_first) todo.erase(todo.begin());
     else todo.pop_back();
-    std::vector<Slot> slots;
+    slots.clear();
     auto add_children = [&](uint32_t b) {
       for (int c = 0; c < 2; c++) {
         if (L.bin[b].ref[c] == RT_FREF_NONE) continue;
@@ -1723,10 +1755,16 @@ int rt_device_count(void) {
 
 int rt_scene_create(const rt_scene_desc* d, rt_scene** out) {
   auto t_create = std::chrono::steady_clock::now();
+  const bool debug_timing = std::getenv("RT_DEBUG_TIMING") != nullptr;
+  auto lap = [&](const char* what) {  // RT_DEBUG_TIMING: where the host side of a scene's creation spends its time
+    if (debug_timing)
+      fprintf(stderr, "[rtcore]   %-10s at %.2f ms\n", what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_create).count());
+  };
   if (!out) return fail(RT_ERR_INVALID_ARGUMENT, "out is NULL");
   *out = nullptr;
   int rc = validate(d);
   if (rc) return rc;
+  lap("validated");
 
   std::vector<int64_t> memo(d->n_nodes, -1);
   uint32_t need = stack_need(d, 0, memo, 0);
@@ -1742,8 +1780,7 @@ int rt_scene_create(const rt_scene_desc* d, rt_scene** out) {
     e.begin = 1 + d->node_child_begin[node];
     e.count = d->node_child_begin[node + 1] - d->node_child_begin[node];
   };
-  std::memset(entries.data(), 0, entries.size() * sizeof(DevEntry));
-  entries[0].ref = RT_MAKE_REF(RT_REF_NODE, 0);
+  entries[0].ref = RT_MAKE_REF(RT_REF_NODE, 0);  // (the vector's elements are value-initialised: all zero)
   fill_node_fields(entries[0], 0);
   for (uint32_t i = 0; i < d->n_child_refs; i++) {
     DevEntry& e = entries[(size_t)i + 1];
@@ -1767,8 +1804,10 @@ int rt_scene_create(const rt_scene_desc* d, rt_scene** out) {
       (*side)[i] = RT_MAKE_REF(RT_REF_NODE, (uint32_t)entries.size());
       entries.push_back(e);
     }
+  lap("entries");
   FastLayout L;
   if (!build_fast_layout(d, L)) return fail(RT_ERR_UNSUPPORTED, L.error);
+  lap("tree");
   if (L.stack_need > RT_FAST_STACK_MAX)
     return fail(RT_ERR_UNSUPPORTED, "the BVH needs a device traversal stack of " + std::to_string(L.stack_need) + " entries; it holds " +
                                         std::to_string(RT_FAST_STACK_MAX));
