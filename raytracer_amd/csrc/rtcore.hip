@@ -1766,6 +1766,20 @@ int rt_scene_create(const rt_scene_desc* d, rt_scene** out) {
   if (rc) return rc;
   lap("validated");
 
+  // The production tree is built on a second thread while this one lays out the reference-order records (both only read
+  // the description; a third of a large scene's creation time each).  Small scenes are not worth a thread.
+  FastLayout L;
+  bool layout_ok = true;
+  std::thread layout_thread;
+  const bool two_threads = d->n_prims >= 4096;
+  if (two_threads) layout_thread = std::thread([&] { layout_ok = build_fast_layout(d, L); });
+  struct JoinOnExit {  // (every return below waits for it)
+    std::thread& t;
+    ~JoinOnExit() {
+      if (t.joinable()) t.join();
+    }
+  } join_on_exit{layout_thread};
+
   std::vector<int64_t> memo(d->n_nodes, -1);
   uint32_t need = stack_need(d, 0, memo, 0);
   if (need < 1) need = 1;
@@ -1805,8 +1819,9 @@ int rt_scene_create(const rt_scene_desc* d, rt_scene** out) {
       entries.push_back(e);
     }
   lap("entries");
-  FastLayout L;
-  if (!build_fast_layout(d, L)) return fail(RT_ERR_UNSUPPORTED, L.error);
+  if (two_threads) layout_thread.join();
+  else layout_ok = build_fast_layout(d, L);
+  if (!layout_ok) return fail(RT_ERR_UNSUPPORTED, L.error);
   lap("tree");
   if (L.stack_need > RT_FAST_STACK_MAX)
     return fail(RT_ERR_UNSUPPORTED, "the BVH needs a device traversal stack of " + std::to_string(L.stack_need) + " entries; it holds " +
