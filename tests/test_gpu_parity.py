@@ -247,6 +247,31 @@ def test_rt_render_with_null_stats_is_the_hook_call():
         check_against_oracle(flat, cam, opt, gpu=a)
 
 
+def test_rt_render_downloads_a_large_image_through_the_staging_block():
+    """rt_render moves images of 16 MiB and more to the caller's buffer through a pinned staging block and several copying
+    threads (download_image): every pixel must arrive, into a fresh buffer and into one that is reused, also right after
+    rt_release_cached_memory has freed the block, and on the several-device path."""
+    torch = _torch()
+    rs = Y.load_scene(scene_path("images", "general/cover"), width=1237, height=911, depth=3, supersampling_level=1)
+    flat, cam, opt = rs.builder.flatten(), rs.camera, rs.options()
+    assert cam.width * cam.height * 24 > (16 << 20)
+    scene = R.DeviceScene(flat)
+    dev = torch.empty((cam.height, cam.width, 3), dtype=torch.float64, device="cuda")
+    scene.render_device(cam, opt, dev.data_ptr())
+    torch.cuda.synchronize()
+    want = dev.cpu().numpy()
+    assert float(want.max()) > 0.
+    for round_ in range(3):
+        got, _ = R.render(flat, cam, opt, want_stats=False)
+        assert np.array_equal(got, want), round_
+        if round_ == 1:
+            N.core_lib().rt_release_cached_memory()
+    o = rs.options()
+    o.n_devices = -1
+    got, _ = R.render(flat, cam, o, want_stats=False)
+    assert np.array_equal(got, want)
+
+
 def test_rt_render_over_several_devices_and_progress(monkeypatch):
     """rt_options.n_devices: the one-process host (animation_renderer.rs:109-122 is a sequential loop in ONE process) reaches
     several GPUs through rt_render itself: tiles dealt cyclically, parts copied to the first device, un-interleaved,
