@@ -441,6 +441,9 @@ __device__ __forceinline__ void flag_sample(const Ws& w, uint32_t root) {
 // the container walk of transparent hits.  A lane whose ray is finished fetches the next one as soon as fewer than
 // RT_REFILL_BELOW lanes of its wavefront are still traversing.
 // ---------------------------------------------------------------------------------------------
+#ifndef RT_TRACE_WAVES_CSG
+#define RT_TRACE_WAVES_CSG 3  // the shadow kernel with the code for CSG objects
+#endif
 #ifndef RT_TRACE_WAVES
 #define RT_TRACE_WAVES 4  // waves per SIMD the trace kernels are compiled for (<= 128 VGPRs)
 #endif
@@ -849,7 +852,7 @@ __device__ __forceinline__ bool shadow_start(const DevScene& s, fast::Trav& T, d
 }
 
 template <bool STATS, bool CSG>
-__global__ __launch_bounds__(64, RT_TRACE_WAVES) void trace_shadow_kernel(DevScene s, Ws w, uint32_t level, uint32_t last_level,
+__global__ __launch_bounds__(64, (CSG && !STATS) ? RT_TRACE_WAVES_CSG : RT_TRACE_WAVES) void trace_shadow_kernel(DevScene s, Ws w, uint32_t level, uint32_t last_level,
                                                                          unsigned long long* stats, uint32_t* overflow_flag) {
   __shared__ uint2 lds_stack[RT_LDS_STACK * 64];
   uint2* lds = lds_stack + (threadIdx.x & 63u);
