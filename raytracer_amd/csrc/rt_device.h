@@ -136,10 +136,21 @@ struct __attribute__((aligned(128))) DevLeafRec {
   double y_min, y_max;
 };
 
+// A CSG object of two analytic primitives with at most two roots each (csg-lens.yml's lens and carved cube): both operands
+// with everything their tests read, side by side, so that the object costs ONE 256-B fetch behind its leaf record instead of
+// the csg_left -> prim_info -> transform / quadric chain per operand and the hit list in scratch (fast::add_csg2).
+// left.flags bits RT_CSG2_OP_SHIFT..: enum rt_csg_op.  left.ref / right.ref: the operands' primitive indices.
+#define RT_LEAFREC_CSG2 64u  // DevLeafRec::flags of a CSG leaf entry: DevLeafRec::material indexes DevScene::csg2_rec
+#define RT_CSG2_OP_SHIFT 16u
+struct __attribute__((aligned(128))) DevCsg2Rec {
+  DevLeafRec left, right;
+};
+
 struct DevScene {
   const DevNode* nodes;       // fast path; node 0 is a synthetic root whose child 0 is the scene's root group
   const uint32_t* leaf_ref;   // fast path: primitive / CSG references of PRIMS leaves
   const DevLeafRec* leaf_rec; // fast path: the same entries with everything an analytic primitive's test reads, 128 B each
+  const DevCsg2Rec* csg2_rec; // fast path: two-primitive CSG objects (RT_LEAFREC_CSG2)
   const uint32_t* prim_rank;  // visit order of each primitive in ObjectGroup::intersect_iter (decides ties in t)
   const DevEntry* entries;    // reference-order path
   const uint4* prim_info;     // x shape, y material, z xform (RT_NONE = none), w geom (triangles: index in leaf order)

@@ -230,6 +230,95 @@ __device__ __forceinline__ void add_csg(const DevScene& s, Trav& T, uint32_t csg
   }
 }
 
+// The same for a CSG object of two analytic primitives with at most two roots each (DevCsg2Rec): both operands' roots from
+// ONE record, the list of at most four in registers.  The reference collects the left operand's roots, then the right's,
+// sorts by t (stable) and filters (csg.rs:87-122): here every root's place in that order is counted directly (the roots
+// before it: smaller t, or equal t and collected earlier).  A NaN root has no place in an order: such a ray takes add_csg.
+template <bool STATS, int MS = MS_ALL>
+__device__ __forceinline__ void add_csg2(const DevScene& s, Trav& T, uint32_t csg_root, uint32_t rec, Counters& cnt) {
+  const DevCsg2Rec* r = s.csg2_rec + rec;
+  const uint32_t lflags = r->left.flags, rflags = r->right.flags, op = lflags >> RT_CSG2_OP_SHIFT;
+  double tl[4], tr[4], ul, vl, ur, vr;
+  const int nl = analytic_roots<STATS>(r->left.shape, lflags, r->left.inv, r->left.y_min, r->left.y_max, T.o, T.d, tl, ul, vl, cnt);
+  const int nr = analytic_roots<STATS>(r->right.shape, rflags, r->right.inv, r->right.y_min, r->right.y_max, T.o, T.d, tr, ur, vr, cnt);
+  // the collection order: left roots, then right roots
+  const double t[4] = {tl[0], tl[1], tr[0], tr[1]};
+  const bool valid[4] = {nl > 0, nl > 1, nr > 0, nr > 1};
+  bool nan = false;
+  for (int i = 0; i < 4; i++) nan = nan || (valid[i] && t[i] != t[i]);
+  if (nan || nl > 2 || nr > 2) {  // (more than two roots cannot happen: rt_scene_create only records such operands)
+    add_csg<STATS, MS>(s, T, csg_root, cnt);
+    return;
+  }
+  int place[4];
+  for (int i = 0; i < 4; i++) {
+    place[i] = 0;
+    for (int j = 0; j < 4; j++)
+      if (j != i && valid[j] && (t[j] < t[i] || (t[j] == t[i] && j < i))) place[i]++;
+  }
+  const int n = nl + nr;
+  // the sorted list, filtered (csg.rs:87-111): position p holds the root whose place is p
+  double st[4];
+  bool sleft[4], keep[4];
+  bool inside_left = false, inside_right = false;
+  for (int p = 0; p < 4; p++) {
+    st[p] = 0.;
+    sleft[p] = false;
+    for (int i = 0; i < 4; i++)
+      if (valid[i] && place[i] == p) {
+        st[p] = t[i];
+        sleft[p] = i < 2;
+      }
+    keep[p] = false;
+    if (p < n) {
+      const bool hit_left = sleft[p];
+      if (hit_left) inside_left = !inside_left;
+      else inside_right = !inside_right;
+      bool allowed;
+      if (op == RT_CSG_UNION) allowed = hit_left ? !inside_right : !inside_left;
+      else if (op == RT_CSG_INTERSECTION) allowed = hit_left ? inside_right : inside_left;
+      else allowed = hit_left ? !inside_right : inside_left;
+      keep[p] = allowed;
+    }
+  }
+  const uint32_t lprim = r->left.ref, rprim = r->right.ref;
+  if (in_mode<MS>(T, M_CONTAINERS)) {
+    // negative-t survivors, aggregated per leaf object, the object whose first one comes first in the list first (add_csg)
+    double nl_t[2] = {0., 0.}, nr_t[2] = {0., 0.};
+    int kl = 0, kr = 0;
+    bool left_first = false, any = false;
+    for (int p = 0; p < 4; p++) {
+      if (!keep[p] || sign_positive(st[p])) continue;
+      if (!any) left_first = sleft[p];
+      any = true;
+      if (sleft[p]) {
+        if (kl == 0) nl_t[0] = st[p];
+        else nl_t[1] = st[p];
+        kl++;
+      } else {
+        if (kr == 0) nr_t[0] = st[p];
+        else nr_t[1] = st[p];
+        kr++;
+      }
+    }
+    if (left_first) {
+      if (kl) add_roots<STATS, MS>(s, T, lprim, 0, kl, nl_t, 0., 0.);
+      if (kr) add_roots<STATS, MS>(s, T, rprim, 0, kr, nr_t, 0., 0.);
+    } else {
+      if (kr) add_roots<STATS, MS>(s, T, rprim, 0, kr, nr_t, 0., 0.);
+      if (kl) add_roots<STATS, MS>(s, T, lprim, 0, kl, nl_t, 0., 0.);
+    }
+  } else {
+    const uint32_t lmat = in_mode<MS>(T, M_SHADOW) ? ((lflags & RT_LEAFREC_OPAQUE) ? RT_MAT_OPAQUE : r->left.material) : 0u;
+    const uint32_t rmat = in_mode<MS>(T, M_SHADOW) ? ((rflags & RT_LEAFREC_OPAQUE) ? RT_MAT_OPAQUE : r->right.material) : 0u;
+    for (int p = 0; p < 4; p++) {
+      if (!keep[p]) continue;
+      const bool L = sleft[p];
+      add_roots<STATS, MS>(s, T, L ? lprim : rprim, L ? lmat : rmat, 1, &st[p], L ? ul : ur, L ? vl : vr);
+    }
+  }
+}
+
 // BoundingBox::intersection_time (bounding_box.rs:192-225) + the exit time.  NaN (0 * inf) is dropped by fmax/fmin like
 // f64::max/min; the reference's early return after x,y is implied by the final test.
 __device__ __forceinline__ bool box_times(const double* __restrict__ bb, d3 o, d3 dinv, double& tmin, double& tmax) {
@@ -689,7 +778,8 @@ __device__ __forceinline__ void trav_run(const DevScene& s, Trav& T, uint2* lds,
           int n = prim_roots<STATS>(s, info, T.o, T.d, ts, u, v, cnt);
           if (n) add_roots<STATS, MS>(s, T, idx, info.y, n, ts, u, v);
         } else if (CSG) {
-          add_csg<STATS, MS>(s, T, idx, cnt);
+          if (h0.w & RT_LEAFREC_CSG2) add_csg2<STATS, MS>(s, T, idx, h0.z, cnt);
+          else add_csg<STATS, MS>(s, T, idx, cnt);
         }
       }
     }

@@ -1931,14 +1931,11 @@ int rt_scene_create(const rt_scene_desc* d, rt_scene** out) {
   UP(L.leaf_ref, leaf_ref);
   {
     std::vector<DevLeafRec> recs(L.leaf_ref.size());
-    for (size_t i = 0; i < recs.size(); i++) {
-      DevLeafRec& r = recs[i];
-      std::memset(&r, 0, sizeof(r));
-      r.ref = L.leaf_ref[i];
-      if ((r.ref >> RT_REF_KIND_SHIFT) != RT_REF_PRIM) continue;
-      uint32_t p = r.ref & RT_REF_INDEX_MASK;
+    std::vector<DevCsg2Rec> csg2;
+    // everything an analytic primitive's test reads; false for triangles (table path, prim_roots)
+    auto fill_inline = [&](DevLeafRec& r, uint32_t p) {
       uint8_t sh = d->prim_shape[p];
-      if (sh == RT_SHAPE_TRIANGLE || sh == RT_SHAPE_SMOOTH_TRIANGLE) continue;  // table path (prim_roots)
+      if (sh == RT_SHAPE_TRIANGLE || sh == RT_SHAPE_SMOOTH_TRIANGLE) return false;
       r.shape = sh;
       r.material = d->prim_material[p];
       r.flags = RT_LEAFREC_INLINE;
@@ -1952,7 +1949,33 @@ int rt_scene_create(const rt_scene_desc* d, rt_scene** out) {
         r.y_max = d->quadric_y_max[d->prim_geom[p]];
         if (d->quadric_closed[d->prim_geom[p]]) r.flags |= RT_LEAFREC_CLOSED;
       }
+      return true;
+    };
+    for (size_t i = 0; i < recs.size(); i++) {
+      DevLeafRec& r = recs[i];
+      std::memset(&r, 0, sizeof(r));
+      r.ref = L.leaf_ref[i];
+      const uint32_t kind = r.ref >> RT_REF_KIND_SHIFT, idx = r.ref & RT_REF_INDEX_MASK;
+      if (kind == RT_REF_PRIM) {
+        fill_inline(r, idx);
+      } else if (kind == RT_REF_CSG) {  // two analytic primitives of at most two roots each: DevCsg2Rec
+        const uint32_t lr = d->csg_left[idx], rr = d->csg_right[idx];
+        if ((lr >> RT_REF_KIND_SHIFT) != RT_REF_PRIM || (rr >> RT_REF_KIND_SHIFT) != RT_REF_PRIM) continue;
+        const uint32_t lp = lr & RT_REF_INDEX_MASK, rp = rr & RT_REF_INDEX_MASK;
+        if (max_roots(d, lp) > 2 || max_roots(d, rp) > 2) continue;
+        DevCsg2Rec c;
+        std::memset(&c, 0, sizeof(c));
+        if (!fill_inline(c.left, lp) || !fill_inline(c.right, rp)) continue;
+        c.left.ref = lp;
+        c.right.ref = rp;
+        c.left.flags |= (uint32_t)d->csg_op[idx] << RT_CSG2_OP_SHIFT;
+        r.flags = RT_LEAFREC_CSG2;
+        r.material = (uint32_t)csg2.size();
+        csg2.push_back(c);
+      }
     }
+    if (csg2.empty()) csg2.emplace_back();  // (never read; keeps the table's pointer valid)
+    UP(csg2, csg2_rec);
     UP(recs, leaf_rec);
   }
   UP(L.prim_rank, prim_rank);

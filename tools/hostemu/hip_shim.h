@@ -77,7 +77,7 @@ static inline hipError_t hipMemcpyPeerAsync(void* d, int, const void* s, int, si
 #define HIP_SYMBOL(x) (&(x))
 template <class T> static inline hipError_t hipGetSymbolAddress(void** p, T* symbol) { *p = (void*)symbol; return hipSuccess; }
 static inline hipError_t hipFree(void* p) { std::free(p); return hipSuccess; }
-enum { hipHostMallocPortable = 1, hipStreamNonBlocking = 1, hipEventDisableTiming = 2 };
+enum { hipHostMallocDefault = 0, hipHostMallocPortable = 1, hipStreamNonBlocking = 1, hipEventDisableTiming = 2 };
 static inline hipError_t hipHostMalloc(void** p, size_t n, unsigned = 0) { *p = std::malloc(n); return hipSuccess; }
 static inline hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) { *s = nullptr; return hipSuccess; }
 static inline hipError_t hipStreamDestroy(hipStream_t) { return hipSuccess; }
