@@ -158,6 +158,43 @@ def test_lights_around_the_scene_one_to_ten():
         assert st["rays_shadow"] + st["rays_shadow_culled"] == st_ref["rays_shadow"] and (n == 1 or st["rays_shadow_culled"] > 0)
 
 
+def test_two_primitive_csg_objects_of_every_kind():
+    """fast::add_csg2 (a CSG object of two analytic primitives, at most two roots each, from one record): every operation over
+    pairs of spheres, cubes, open cylinders and cones and planes at seeded random placements, glass and opaque, against the
+    oracle and against the reference-order render (both evaluate CSG objects by the general list code); closed cylinders
+    (four roots) keep the general path and ride along."""
+    import random
+    rnd = random.Random(20250611)
+    shapes = [(N.SPHERE, {}), (N.CUBE, {}), (N.CYLINDER, dict(y_min=-0.7, y_max=0.9)), (N.CONE, dict(y_min=-0.8, y_max=0.6)),
+              (N.PLANE, {}), (N.CYLINDER, dict(y_min=-0.5, y_max=0.5, closed=True))]
+
+    def placed():
+        return S.matrix_from_transformations([
+            S.Transformation.scaling(rnd.uniform(0.6, 1.3), rnd.uniform(0.6, 1.3), rnd.uniform(0.6, 1.3)),
+            S.Transformation.rotation(rnd.randrange(3), rnd.uniform(-1.5, 1.5)),
+            S.Transformation.translation(rnd.uniform(-0.5, 0.5), rnd.uniform(-0.4, 0.4), rnd.uniform(-0.5, 0.5))])
+
+    for op in (N.CSG_UNION, N.CSG_INTERSECTION, N.CSG_DIFFERENCE):
+        for _ in range(4):
+            (sl, kl), (sr, kr) = rnd.choice(shapes), rnd.choice(shapes)
+            sb = S.SceneBuilder()
+            glass = S.Material.glass()
+            red = S.Material(S.Pattern(N.P_CONST, (0.9, 0.3, 0.2)), reflectivity=0.25)
+            left = sb.primitive(sl, rnd.choice((glass, red)), placed(), **kl)
+            right = sb.primitive(sr, rnd.choice((glass, red)), placed(), **kr)
+            sb.add_object(sb.csg(op, left, right))
+            sb.add_object(sb.primitive(N.PLANE, S.Material(S.Pattern(N.P_CONST, (0.5, 0.6, 0.5))), translation(0., -2.5, 0.)))
+            sb.add_light((-4., 6., -5.), (0.7, 0.7, 0.7))
+            sb.add_light((5., 3., -2.), (0.3, 0.3, 0.3))
+            cam = S.make_camera(56, 48, 1.1, S.view_transformation((0.3, 1.2, -4.5), (0, 0, 0), (0, 1, 0)))
+            opt = S.make_options(supersampling_level=1, max_depth=4, shadow_intensity=True)
+            flat = sb.flatten()
+            gpu, _ = R.render(flat, cam, opt)
+            check_against_oracle(flat, cam, opt, gpu=gpu)
+            ref, _ = R.render(flat, cam, _ref_order(opt))
+            assert float(np.abs(gpu - ref).max()) < 1e-12, (op, sl, sr)
+
+
 def test_invalid_arguments_fail_loudly():
     sb = default_testing_builder()
     flat = sb.flatten()
