@@ -850,6 +850,13 @@ __device__ __forceinline__ bool shadow_start(const DevScene& s, fast::Trav& T, d
   fast::trav_start(T, over, sdir, fast::M_SHADOW, dist);
   return true;
 }
+// The same for an item lit_bits has already found lit (the decision is exact there): the normal is not read again.
+__device__ __forceinline__ void shadow_start_lit(const DevScene& s, fast::Trav& T, d3 over, uint32_t l) {
+  const double* lp = s.light_pos + (size_t)l * 3;
+  d3 vv = sub3(mk3(lp[0], lp[1], lp[2]), over);
+  double dist = mag3(vv);
+  fast::trav_start(T, over, normalize3(vv), fast::M_SHADOW, dist);
+}
 
 template <bool STATS, bool CSG>
 __global__ __launch_bounds__(64, (CSG && !STATS) ? RT_TRACE_WAVES_CSG : RT_TRACE_WAVES) void trace_shadow_kernel(DevScene s, Ws w, uint32_t level, uint32_t last_level,
@@ -864,6 +871,7 @@ __global__ __launch_bounds__(64, (CSG && !STATS) ? RT_TRACE_WAVES_CSG : RT_TRACE
   const uint32_t node0 = level == 0 ? 0u : w.ctrl->level_end[level - 1];
   const uint32_t n_nodes = w.ctrl->level_end[last_level] - node0, n_items = n_nodes * s.n_lights;  // (< 2^32: ensure_workspace)
   const size_t cap = w.cap_nodes;
+  const bool all_lit = s.n_lights > RT_LIT_LIGHTS;  // more lights than node_lit has bits: shadow_start decides
   fast::Trav T;
   T.cur = RT_FREF_NONE;
   T.sp = 0;
@@ -878,20 +886,25 @@ __global__ __launch_bounds__(64, (CSG && !STATS) ? RT_TRACE_WAVES_CSG : RT_TRACE
   for (;;) {
     bool want = my == RT_NONE && !exhausted;
     if (__builtin_amdgcn_ballot_w64(want) != 0ull) {
-      uint32_t id = lit_take<STATS>(w, w.ctrl->shadow_fetch[level], n_items, n_nodes, node0, s.n_lights > RT_LIT_LIGHTS, cursor, window, want, cnt);
+      uint32_t id = lit_take<STATS>(w, w.ctrl->shadow_fetch[level], n_items, n_nodes, node0, all_lit, cursor, window, want, cnt);
       if (want) {
         if (id != RT_NONE) {
           light = id / n_nodes;
           my = node0 + (id - light * n_nodes);
           const double* nf = w.node_f + my;
           d3 over = mk3(ld_stream(nf + (NF_OVER + 0) * cap), ld_stream(nf + (NF_OVER + 1) * cap), ld_stream(nf + (NF_OVER + 2) * cap));
-          d3 normal = mk3(ld_stream(nf + (NF_NORMAL + 0) * cap), ld_stream(nf + (NF_NORMAL + 1) * cap), ld_stream(nf + (NF_NORMAL + 2) * cap));
-          if (shadow_start(s, T, over, normal, light)) {
+          if (!all_lit) {  // lit_take hands out lit items only
+            shadow_start_lit(s, T, over, light);
             if (STATS) cnt.rays_shadow++;
-          } else {  // the light is behind the surface: no ray
-            if (STATS) cnt.shadow_culled++;
-            st_stream(&w.shadow[(size_t)light * cap + my], 0.);
-            my = RT_NONE;
+          } else {
+            d3 normal = mk3(ld_stream(nf + (NF_NORMAL + 0) * cap), ld_stream(nf + (NF_NORMAL + 1) * cap), ld_stream(nf + (NF_NORMAL + 2) * cap));
+            if (shadow_start(s, T, over, normal, light)) {
+              if (STATS) cnt.rays_shadow++;
+            } else {  // the light is behind the surface: no ray
+              if (STATS) cnt.shadow_culled++;
+              st_stream(&w.shadow[(size_t)light * cap + my], 0.);
+              my = RT_NONE;
+            }
           }
         } else {
           exhausted = true;
