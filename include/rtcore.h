@@ -66,7 +66,8 @@ enum rt_status {
   RT_ERR_INVALID_ARGUMENT = -1, /* NULL where data is required, inconsistent counts, bad refs   */
   RT_ERR_UNSUPPORTED = -2,      /* scene exceeds a documented device limit      */
   RT_ERR_DEVICE = -3,           /* a HIP call failed, or no gfx950 device is usable             */
-  RT_ERR_OVERFLOW = -4          /* a per-ray bounded list overflowed while rendering            */
+  RT_ERR_OVERFLOW = -4,         /* a per-ray bounded list overflowed while rendering            */
+  RT_ERR_HOST = -5              /* host memory or threads exhausted (no C++ exception ever leaves the library) */
 };
 
 /* Material scalars, in the order of `struct Material` (src/scene/object/material.rs:10-20). */

@@ -9,9 +9,11 @@
 #include <cstring>
 #include <algorithm>
 #include <chrono>
+#include <memory>
 #include <mutex>
 #include <thread>
 #include <cstddef>
+#include <exception>
 #include <new>
 #include <string>
 #include <utility>
@@ -255,6 +257,30 @@ int fail(int code, const std::string& msg) {
   g_err = msg;
   return code;
 }
+
+// No exception leaves the library: the callers are C and Rust, where an unwinding C++ exception is
+// undefined behaviour.  Every extern "C" entry point that can allocate on the host or start a thread is a function-try-block
+// ending in RT_NO_UNWIND: std::bad_alloc (a scene's tables) and std::system_error (no thread to be had) become RT_ERR_HOST.
+int fail_host(const char* what) noexcept {
+  try {
+    g_err = std::string("host resources exhausted: ") + what;
+  } catch (...) {
+    g_err.clear();  // (noexcept)
+  }
+  return RT_ERR_HOST;
+}
+#define RT_NO_UNWIND                                                          \
+  catch (const std::exception& e) { return fail_host(e.what()); }            \
+  catch (...) { return fail_host("unknown exception"); }
+
+// Host threads that are joined on every path out of their scope (a std::thread destroyed while joinable terminates).
+struct JoinAll {
+  std::vector<std::thread>& v;
+  ~JoinAll() {
+    for (std::thread& t : v)
+      if (t.joinable()) t.join();
+  }
+};
 
 #define HIP_TRY(expr)                                                                              \
   do {                                                                                             \
@@ -1660,7 +1686,7 @@ hipError_t download_image(void* dst, const void* d_src, size_t bytes) {
     if (g_download_stage.p) (void)hipHostFree(g_download_stage.p);
     g_download_stage.p = nullptr;
     g_download_stage.cap = 0;
-    if (hipHostMalloc(&g_download_stage.p, bytes, hipHostMallocDefault) != hipSuccess) {
+    if (hipHostMalloc(&g_download_stage.p, bytes, hipHostMallocPortable) != hipSuccess) {
       (void)hipGetLastError();
       g_download_stage.p = nullptr;
       return hipMemcpy(dst, d_src, bytes, hipMemcpyDeviceToHost);  // no pinned memory to be had: the plain way
@@ -1671,6 +1697,7 @@ hipError_t download_image(void* dst, const void* d_src, size_t bytes) {
   if (e != hipSuccess) return e;
   const size_t per = (bytes / n + 4095) & ~(size_t)4095;
   std::vector<std::thread> workers;
+  JoinAll join{workers};
   for (size_t k = 1; k < n; k++)
     workers.emplace_back([&, k] {
       const size_t at = k * per;
@@ -1726,6 +1753,7 @@ int render_on_devices(const std::vector<int>& devs, const rt_scene_desc* desc, c
   std::vector<std::string> errs(n);
   std::vector<rt_stats> part_stats(n);
   std::vector<std::thread> workers;
+  JoinAll join{workers};
   for (uint32_t k = 0; k < n; k++)
     workers.emplace_back([&, k]() {
       auto run = [&]() -> int {
@@ -1765,7 +1793,11 @@ int render_on_devices(const std::vector<int>& devs, const rt_scene_desc* desc, c
         absorb_summary(sc);
         return r;
       };
-      rcs[k] = run();
+      try {
+        rcs[k] = run();
+      } catch (const std::exception& e) {  // (nothing may unwind out of a thread either)
+        rcs[k] = fail_host(e.what());
+      }
       if (rcs[k]) errs[k] = g_err;  // (g_err is per thread)
     });
   for (std::thread& t : workers) t.join();
@@ -1791,7 +1823,7 @@ extern "C" {
 uint32_t rt_abi_version(void) { return RT_ABI_VERSION; }
 const char* rt_last_error(void) { return g_err.c_str(); }
 
-int rt_device_count(void) {
+int rt_device_count(void) try {
   int n = 0;
   hipError_t e = hipGetDeviceCount(&n);
   if (e != hipSuccess) {
@@ -1799,9 +1831,9 @@ int rt_device_count(void) {
     return RT_ERR_DEVICE;
   }
   return n;
-}
+} RT_NO_UNWIND
 
-int rt_scene_create(const rt_scene_desc* d, rt_scene** out) {
+int rt_scene_create(const rt_scene_desc* d, rt_scene** out) try {
   auto t_create = std::chrono::steady_clock::now();
   const bool debug_timing = std::getenv("RT_DEBUG_TIMING") != nullptr;
   auto lap = [&](const char* what) {  // RT_DEBUG_TIMING: where the host side of a scene's creation spends its time
@@ -1820,13 +1852,21 @@ int rt_scene_create(const rt_scene_desc* d, rt_scene** out) {
   bool layout_ok = true;
   std::thread layout_thread;
   const bool two_threads = d->n_prims >= 4096;
-  if (two_threads) layout_thread = std::thread([&] { layout_ok = build_fast_layout(d, L); });
   struct JoinOnExit {  // (every return below waits for it)
     std::thread& t;
     ~JoinOnExit() {
       if (t.joinable()) t.join();
     }
   } join_on_exit{layout_thread};
+  bool layout_threw = false;
+  if (two_threads)
+    layout_thread = std::thread([&] {
+      try {
+        layout_ok = build_fast_layout(d, L);
+      } catch (...) {  // (nothing may unwind out of a thread: reported below as RT_ERR_HOST)
+        layout_threw = true;
+      }
+    });
 
   std::vector<int64_t> memo(d->n_nodes, -1);
   uint32_t need = stack_need(d, 0, memo, 0);
@@ -1869,6 +1909,7 @@ int rt_scene_create(const rt_scene_desc* d, rt_scene** out) {
   lap("entries");
   if (two_threads) layout_thread.join();
   else layout_ok = build_fast_layout(d, L);
+  if (layout_threw) return fail_host("laying out the scene's tree");
   if (!layout_ok) return fail(RT_ERR_UNSUPPORTED, L.error);
   lap("tree");
   if (L.stack_need > RT_FAST_STACK_MAX)
@@ -1907,7 +1948,8 @@ int rt_scene_create(const rt_scene_desc* d, rt_scene** out) {
 
   if (std::getenv("RT_DEBUG_TIMING"))
     fprintf(stderr, "[rtcore] layout: %.2f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_create).count());
-  rt_scene* sc = new rt_scene();
+  std::unique_ptr<rt_scene> owner(new rt_scene());  // (destroyed on every path but the last)
+  rt_scene* sc = owner.get();
   t_stage.size = 0;
   sc->stage = &t_stage;
   (void)hipGetDevice(&sc->device);
@@ -1916,10 +1958,7 @@ int rt_scene_create(const rt_scene_desc* d, rt_scene** out) {
 #define UP(vec, field)                                 \
   do {                                                 \
     rc = upload(sc, vec, &sc->dev.field);              \
-    if (rc) {                                          \
-      delete sc;                                       \
-      return rc;                                       \
-    }                                                  \
+    if (rc) return rc;                                 \
   } while (0)
 #define UPA(T, ptr, n, field)                          \
   do {                                                 \
@@ -2035,13 +2074,10 @@ int rt_scene_create(const rt_scene_desc* d, rt_scene** out) {
     rc = fail(RT_ERR_DEVICE, "creation of the scene's side stream failed");
   for (uint32_t l = 0; rc == RT_OK && l <= RT_MAX_DEPTH; l++)
     if (hipEventCreateWithFlags(&sc->level_event[l], hipEventDisableTiming) != hipSuccess) rc = fail(RT_ERR_DEVICE, "hipEventCreate failed");
-  if (rc) {
-    delete sc;
-    return rc;
-  }
-  *out = sc;
+  if (rc) return rc;
+  *out = owner.release();
   return RT_OK;
-}
+} RT_NO_UNWIND
 
 void rt_scene_destroy(rt_scene* scene) { delete scene; }
 
@@ -2057,16 +2093,16 @@ uint32_t rt_tile_count(uint32_t width, uint32_t height, uint32_t part, uint32_t 
 }
 
 int rt_render_tiles_device(const rt_scene* scene, const rt_camera* camera, const rt_options* options, uint32_t part,
-                           uint32_t n_parts, double* d_out_tiles, void* hip_stream, rt_stats* stats) {
+                           uint32_t n_parts, double* d_out_tiles, void* hip_stream, rt_stats* stats) try {
   return launch_render(scene, camera, options, part, n_parts, 1, d_out_tiles, (hipStream_t)hip_stream, stats);
-}
+} RT_NO_UNWIND
 
 int rt_render_device(const rt_scene* scene, const rt_camera* camera, const rt_options* options, double* d_out_rgb, void* hip_stream,
-                     rt_stats* stats) {
+                     rt_stats* stats) try {
   return launch_render(scene, camera, options, 0, 1, 0, d_out_rgb, (hipStream_t)hip_stream, stats);
-}
+} RT_NO_UNWIND
 
-int rt_render_device_noalloc(const rt_scene* scene, const rt_camera* camera, const rt_options* options, double* d_out_rgb, void* hip_stream) {
+int rt_render_device_noalloc(const rt_scene* scene, const rt_camera* camera, const rt_options* options, double* d_out_rgb, void* hip_stream) try {
   int rc = check_render_args(scene, camera, options);
   if (rc) return rc;
   if (!d_out_rgb) return fail(RT_ERR_INVALID_ARGUMENT, "output buffer is NULL");
@@ -2109,10 +2145,10 @@ int rt_render_device_noalloc(const rt_scene* scene, const rt_camera* camera, con
   scene->rendered = true;
   HIP_TRY(hipEventRecord(scene->done_event, st));
   return RT_OK;
-}
+} RT_NO_UNWIND
 
 int rt_assemble_tiles_device(uint32_t width, uint32_t height, uint32_t n_parts, uint32_t part_stride_tiles,
-                             const double* d_tiles_all_parts, double* d_out_rgb, void* hip_stream) {
+                             const double* d_tiles_all_parts, double* d_out_rgb, void* hip_stream) try {
   if (!d_tiles_all_parts || !d_out_rgb || n_parts == 0 || width == 0 || height == 0)
     return fail(RT_ERR_INVALID_ARGUMENT, "bad arguments to rt_assemble_tiles_device");
   uint32_t tiles_x;
@@ -2122,19 +2158,19 @@ int rt_assemble_tiles_device(uint32_t width, uint32_t height, uint32_t n_parts, 
                      height, n_parts, part_stride_tiles, tiles_x, n_tiles, d_tiles_all_parts, d_out_rgb);
   HIP_TRY(hipGetLastError());
   return RT_OK;
-}
+} RT_NO_UNWIND
 
-int rt_quantize_device(const double* d_rgb, uint64_t n_values, uint8_t* d_out_u8, void* hip_stream) {
+int rt_quantize_device(const double* d_rgb, uint64_t n_values, uint8_t* d_out_u8, void* hip_stream) try {
   if (!d_rgb || !d_out_u8) return fail(RT_ERR_INVALID_ARGUMENT, "bad arguments to rt_quantize_device");
   if (n_values == 0) return RT_OK;
   hipLaunchKernelGGL(quantize_kernel, dim3((unsigned)((n_values + 255) / 256)), dim3(256), 0, (hipStream_t)hip_stream, d_rgb,
                      n_values, d_out_u8);
   HIP_TRY(hipGetLastError());
   return RT_OK;
-}
+} RT_NO_UNWIND
 
 int rt_trace_rays(const rt_scene* scene, const rt_options* options, uint32_t n, const double* origin, const double* direction,
-                  double* out_rgb) {
+                  double* out_rgb) try {
   if (!scene || !options || !origin || !direction || !out_rgb) return fail(RT_ERR_INVALID_ARGUMENT, "bad arguments to rt_trace_rays");
   if (options->max_depth > RT_MAX_DEPTH) return fail(RT_ERR_UNSUPPORTED, "max_depth exceeds RT_MAX_DEPTH");
   if (n == 0) return RT_OK;
@@ -2192,9 +2228,9 @@ int rt_trace_rays(const rt_scene* scene, const rt_options* options, uint32_t n, 
     if (ovf) rc = fail(RT_ERR_OVERFLOW, "a per-ray bounded list overflowed on the device");
   } while (0);
   return rc;
-}
+} RT_NO_UNWIND
 
-int rt_render(const rt_scene_desc* scene_desc, const rt_camera* camera, const rt_options* options, double* out_rgb, rt_stats* stats) {
+int rt_render(const rt_scene_desc* scene_desc, const rt_camera* camera, const rt_options* options, double* out_rgb, rt_stats* stats) try {
   if (!out_rgb || !camera) return fail(RT_ERR_INVALID_ARGUMENT, "out_rgb and camera are required");
   if (!scene_desc || !options) return fail(RT_ERR_INVALID_ARGUMENT, "scene and options are required");
   {
@@ -2250,6 +2286,6 @@ int rt_render(const rt_scene_desc* scene_desc, const rt_camera* camera, const rt
   // (the download has waited for the frame: its summary is in; ~rt_scene remembers what it says about this kind of scene)
   absorb_summary(sc);
   return rc;
-}
+} RT_NO_UNWIND
 
 }  // extern "C"
