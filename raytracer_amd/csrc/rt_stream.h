@@ -763,13 +763,21 @@ __global__ __launch_bounds__(256, RT_SHADE_WAVES) void shade_kernel(DevScene s, 
   uint32_t parity = 0;
   const uint32_t wv = threadIdx.x >> 6, lane = threadIdx.x & 63u;
   // (the loop is uniform over the BLOCK: its wavefronts meet at barriers)
+  // (what each ray of a span hit is fetched one iteration ahead: the fetch was the first link of an iteration's chain of
+  // memory round trips — hit list, node records, the hit's tables, child rays' slots — which is what this kernel waits on)
+  uint32_t ahead[PER];
+  for (uint32_t k = 0; k < PER; k++) {
+    uint32_t id = blockIdx.x * RT_SHADE_SPAN + k * 256u + threadIdx.x;
+    ahead[k] = id < n_rays ? prims[id] : RT_NONE;
+  }
   for (uint32_t bbase = blockIdx.x * RT_SHADE_SPAN; bbase < n_rays; bbase += gridDim.x * RT_SHADE_SPAN) {
     unsigned long long hm[PER];
     for (uint32_t k = 0; k < PER; k++) {
-      uint32_t id = bbase + k * 256u + threadIdx.x;
-      bool hit = id < n_rays && prims[id] != RT_NONE;
+      bool hit = ahead[k] != RT_NONE;
       hm[k] = __builtin_amdgcn_ballot_w64(hit);
       if (lane == 0) sh_count[k * 4 + wv] = (uint32_t)__builtin_popcountll(hm[k]);
+      unsigned long long id = (unsigned long long)bbase + (unsigned long long)gridDim.x * RT_SHADE_SPAN + k * 256u + threadIdx.x;
+      ahead[k] = id < n_rays ? prims[id] : RT_NONE;
     }
     __syncthreads();
     uint32_t total = 0, before[PER];
@@ -931,7 +939,7 @@ __global__ __launch_bounds__(64, (CSG && !STATS) ? RT_TRACE_WAVES_CSG : RT_TRACE
 // combine: Integrator::shade_hit_at_depth (integrator.rs:199-228) for every node of one level, deepest level first.
 // ---------------------------------------------------------------------------------------------
 #ifndef RT_COMBINE_WAVES
-#define RT_COMBINE_WAVES 3  // 150 registers, no spills; 4 (128 registers, 17 spilled): 2.55 -> 3.29 ms on the 4K frame
+#define RT_COMBINE_WAVES 4  // 128 registers, 4 spilled: 2.34 -> 2.10 ms on the 4K frame against 3 (138 registers, none spilled)
 #endif
 __global__ __launch_bounds__(256, RT_COMBINE_WAVES) void combine_kernel(DevScene s, DevOptions opt, Ws w, uint32_t level) {
   const uint32_t begin = level == 0 ? 0u : w.ctrl->level_end[level - 1], end = w.ctrl->level_end[level];
@@ -964,10 +972,11 @@ __global__ __launch_bounds__(256, RT_COMBINE_WAVES) void combine_kernel(DevScene
       rr = add3(reflected, refracted);
     }
     d3 acc = mk3(0., 0., 0.);
+    const d3 surface_color = pattern_color(s, info, over);  // (the same for every light)
     for (uint32_t l = 0; l < s.n_lights; l++) {
       double shadow = fmin(w.shadow[(size_t)l * cap + node], 1.);  // IntersectionCollector::shadow_intensity (intersection.rs:124-126)
       if (!opt.shadow_intensity) shadow = approx_eq(shadow, 0.) ? 0. : 1.;
-      d3 surface = lighting(s, l, info, mat, over, eye, normal, shadow);
+      d3 surface = lighting_of(s, l, surface_color, mat, over, eye, normal, shadow);
       acc = add3(add3(acc, surface), rr);  // acc + surface + reflected_refracted
     }
     double* dst;
