@@ -713,18 +713,21 @@ __device__ __forceinline__ void store_children(const Ws& w, double* __restrict__
   }
 }
 
-// A block looks at RT_SHADE_SPAN rays per iteration, packs the ones that hit (in ray order) into a list in LDS, takes
+// A block looks at SPAN rays per iteration (RT_SHADE_SPAN, or RT_SHADE_SPAN_BIG for big batches), packs the ones that hit (in ray order) into a list in LDS, takes
 // their node records with ONE atomic, and then shades 256 hits at a time, again with one atomic per pass for the queue
 // slots of their child rays.  Atomics on one address complete one after the other (about 9 ns each here): with one per
 // wavefront for the nodes and one for the children they were more than half of the kernel's time.  Node records of a
 // span are consecutive and in ray order, which keeps neighbouring shadow rays in one wavefront later.
 #ifndef RT_SHADE_SPAN
-#define RT_SHADE_SPAN 256u  // 256 .. 2048 shade equally fast; a small frame's shadow rays are 20 % faster behind 256 (its
-#endif                      // node records then interleave image regions finely, which balances the shadow kernel's grabs)
+#define RT_SHADE_SPAN 256u  // small batches: their shadow rays are faster behind 256 (the node records then interleave image
+#endif                      // regions finely, which balances the shadow kernel's grabs: 1080p ss 4 5.4 against 5.8 ms behind 1024)
+#ifndef RT_SHADE_SPAN_BIG
+#define RT_SHADE_SPAN_BIG 1024u  // batches of RT_SHADE_BIG_SAMPLES samples and more: a quarter of the same-address atomics, and
+#endif                           // longer runs of neighbouring node records (4K frame: shade 3.8 -> 3.5 ms, shadow rays 13.1 -> 12.9)
 #ifndef RT_SHADE_WAVES
 #define RT_SHADE_WAVES 4
 #endif
-template <bool CAMERA, bool STATS>
+template <bool CAMERA, bool STATS, uint32_t SPAN>
 __global__ __launch_bounds__(256, RT_SHADE_WAVES) void shade_kernel(DevScene s, rt_camera cam, DevOptions opt, Ws w, Batch b, uint32_t level,
                                                     unsigned long long* stats, uint32_t* overflow_flag) {
   Counters cnt = {};
@@ -755,8 +758,8 @@ __global__ __launch_bounds__(256, RT_SHADE_WAVES) void shade_kernel(DevScene s, 
                             out.want_refract ? 1ull : 0ull, node, root, out, cnt);
   }
 #else
-  constexpr uint32_t PER = RT_SHADE_SPAN / 256u;  // rays a thread looks at per iteration
-  __shared__ uint32_t sh_ids[RT_SHADE_SPAN];     // the span's hits: ray index within the span, in ray order
+  constexpr uint32_t PER = SPAN / 256u;  // rays a thread looks at per iteration
+  __shared__ uint32_t sh_ids[SPAN];     // the span's hits: ray index within the span, in ray order
   __shared__ uint32_t sh_count[PER * 4];          // hits of (sub-span k, wavefront wv) at [k * 4 + wv]
   __shared__ uint32_t sh_base;
   __shared__ uint32_t sh_children[2][4], sh_child_base[2];  // double-buffered by shading pass
@@ -767,16 +770,16 @@ __global__ __launch_bounds__(256, RT_SHADE_WAVES) void shade_kernel(DevScene s, 
   // memory round trips — hit list, node records, the hit's tables, child rays' slots — which is what this kernel waits on)
   uint32_t ahead[PER];
   for (uint32_t k = 0; k < PER; k++) {
-    uint32_t id = blockIdx.x * RT_SHADE_SPAN + k * 256u + threadIdx.x;
+    uint32_t id = blockIdx.x * SPAN + k * 256u + threadIdx.x;
     ahead[k] = id < n_rays ? prims[id] : RT_NONE;
   }
-  for (uint32_t bbase = blockIdx.x * RT_SHADE_SPAN; bbase < n_rays; bbase += gridDim.x * RT_SHADE_SPAN) {
+  for (uint32_t bbase = blockIdx.x * SPAN; bbase < n_rays; bbase += gridDim.x * SPAN) {
     unsigned long long hm[PER];
     for (uint32_t k = 0; k < PER; k++) {
       bool hit = ahead[k] != RT_NONE;
       hm[k] = __builtin_amdgcn_ballot_w64(hit);
       if (lane == 0) sh_count[k * 4 + wv] = (uint32_t)__builtin_popcountll(hm[k]);
-      unsigned long long id = (unsigned long long)bbase + (unsigned long long)gridDim.x * RT_SHADE_SPAN + k * 256u + threadIdx.x;
+      unsigned long long id = (unsigned long long)bbase + (unsigned long long)gridDim.x * SPAN + k * 256u + threadIdx.x;
       ahead[k] = id < n_rays ? prims[id] : RT_NONE;
     }
     __syncthreads();

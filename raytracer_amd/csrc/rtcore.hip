@@ -1327,6 +1327,9 @@ struct TimedLaunch {  // records an event before and after one launch when the s
 #ifndef RT_SHADOW_SIDE_SAMPLES
 #define RT_SHADOW_SIDE_SAMPLES (64u << 20)
 #endif
+#ifndef RT_SHADE_BIG_SAMPLES
+#define RT_SHADE_BIG_SAMPLES (64u << 20)  // (rt_stream.h, RT_SHADE_SPAN_BIG)
+#endif
 #ifndef RT_RETRACE_BLOCKS_PER_CU
 #define RT_RETRACE_BLOCKS_PER_CU 16u  // few rays, long dependent walks: 4 -> 16 blocks per CU took 1.85 -> 1.35 ms off the 4K frame
 #endif
@@ -1378,8 +1381,12 @@ int run_stream_batch(const rt_scene* sc, const stream::Ws& w, const rt_camera& c
     }
     {
       TimedLaunch t(sc, st, TC_SHADE);
-      hipLaunchKernelGGL((stream::shade_kernel<CAMERA, STATS>), dim3(level == 0 ? first_grid : wide_grid), dim3(256), 0, st, sc->dev,
-                         cam, dopt, w, b, level, sc->d_stats, sc->d_overflow);
+      if (b.n_samples >= RT_SHADE_BIG_SAMPLES)
+        hipLaunchKernelGGL((stream::shade_kernel<CAMERA, STATS, RT_SHADE_SPAN_BIG>), dim3(level == 0 ? first_grid : wide_grid), dim3(256), 0, st,
+                           sc->dev, cam, dopt, w, b, level, sc->d_stats, sc->d_overflow);
+      else
+        hipLaunchKernelGGL((stream::shade_kernel<CAMERA, STATS, RT_SHADE_SPAN>), dim3(level == 0 ? first_grid : wide_grid), dim3(256), 0, st,
+                           sc->dev, cam, dopt, w, b, level, sc->d_stats, sc->d_overflow);
     }
     {
       TimedLaunch t(sc, st, TC_OTHER);
