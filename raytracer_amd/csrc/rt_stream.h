@@ -687,14 +687,14 @@ __device__ __forceinline__ void shade_hit(const DevScene& s, const rt_camera& ca
   nu[NU_ROOT * cap] = root;
 }
 
-// The rays of level + 1 of one wavefront, stored from queue slot `base` on: its reflected rays first, then its refracted
-// rays (called by all its lanes; m1 / m2 = the wavefront's lanes that want each).
+// The rays of level + 1 of one wavefront: its reflected rays from queue slot `base_reflect` on, its refracted rays from
+// `base_refract` on (called by all its lanes; m1 / m2 = the wavefront's lanes that want each).
 template <bool STATS>
-__device__ __forceinline__ void store_children(const Ws& w, double* __restrict__ next, uint32_t base, unsigned long long m1,
-                                               unsigned long long m2, uint32_t node, uint32_t root, const ShadeOut& out, Counters& cnt) {
-  const uint32_t n1c = (uint32_t)__builtin_popcountll(m1);
+__device__ __forceinline__ void store_children(const Ws& w, double* __restrict__ next, uint32_t base_reflect, uint32_t base_refract,
+                                               unsigned long long m1, unsigned long long m2, uint32_t node, uint32_t root,
+                                               const ShadeOut& out, Counters& cnt) {
   if (out.want_reflect) {
-    uint32_t k = base + rank_in(m1);
+    uint32_t k = base_reflect + rank_in(m1);
     if (k < w.cap_rays) {
       store_ray(next, k, out.child_o[0], out.child_d[0], node, root);
       if (STATS) cnt.rays_reflect++;
@@ -703,7 +703,7 @@ __device__ __forceinline__ void store_children(const Ws& w, double* __restrict__
     }
   }
   if (out.want_refract) {
-    uint32_t k = base + n1c + rank_in(m2);
+    uint32_t k = base_refract + rank_in(m2);
     if (k < w.cap_rays) {
       store_ray(next, k, out.child_o[1], out.child_d[1], node | RT_PARENT_REFRACT, root);
       if (STATS) cnt.rays_refract++;
@@ -753,16 +753,18 @@ __global__ __launch_bounds__(256, RT_SHADE_WAVES) void shade_kernel(DevScene s, 
     ShadeOut out = {};
     shade_hit<CAMERA, STATS>(s, cam, opt, w, b, level, queue, id, prim, node, root, out, cnt);
     uint32_t n_children = (out.want_reflect ? 1u : 0u) + (out.want_refract ? 1u : 0u);
-    if (n_children)
-      store_children<STATS>(w, next, atomicAdd(&w.ctrl->n_rays[level + 1], n_children), out.want_reflect ? 1ull : 0ull,
+    if (n_children) {
+      const uint32_t cbase = atomicAdd(&w.ctrl->n_rays[level + 1], n_children);
+      store_children<STATS>(w, next, cbase, cbase + (out.want_reflect ? 1u : 0u), out.want_reflect ? 1ull : 0ull,
                             out.want_refract ? 1ull : 0ull, node, root, out, cnt);
+    }
   }
 #else
   constexpr uint32_t PER = SPAN / 256u;  // rays a thread looks at per iteration
   __shared__ uint32_t sh_ids[SPAN];     // the span's hits: ray index within the span, in ray order
   __shared__ uint32_t sh_count[PER * 4];          // hits of (sub-span k, wavefront wv) at [k * 4 + wv]
   __shared__ uint32_t sh_base;
-  __shared__ uint32_t sh_children[2][4], sh_child_base[2];  // double-buffered by shading pass
+  __shared__ uint32_t sh_children[2][2][4], sh_child_base[2];  // [pass parity][reflected / refracted][wavefront]
   uint32_t parity = 0;
   const uint32_t wv = threadIdx.x >> 6, lane = threadIdx.x & 63u;
   // (the loop is uniform over the BLOCK: its wavefronts meet at barriers)
@@ -814,19 +816,29 @@ __global__ __launch_bounds__(256, RT_SHADE_WAVES) void shade_kernel(DevScene s, 
         }
       }
       // queue slots of the block's child rays: one atomic per 256 hits (one per wavefront was a third more shade time:
-      // every one of them goes to the same address), wavefront after wavefront
+      // every one of them goes to the same address).  The pass's reflected rays come first, wavefront after wavefront, then
+      // its refracted rays: a wavefront of the next level's trace kernel then mostly holds rays of one kind, which travel
+      // alike (reflected and refracted rays of the same hits leave in opposite directions).
       unsigned long long m1 = __builtin_amdgcn_ballot_w64(out.want_reflect), m2 = __builtin_amdgcn_ballot_w64(out.want_refract);
-      if (lane == 0) sh_children[parity][wv] = (uint32_t)(__builtin_popcountll(m1) + __builtin_popcountll(m2));
-      __syncthreads();
-      if (threadIdx.x == 0) {
-        uint32_t all = sh_children[parity][0] + sh_children[parity][1] + sh_children[parity][2] + sh_children[parity][3];
-        sh_child_base[parity] = all ? atomicAdd(&w.ctrl->n_rays[level + 1], all) : 0u;
+      if (lane == 0) {
+        sh_children[parity][0][wv] = (uint32_t)__builtin_popcountll(m1);
+        sh_children[parity][1][wv] = (uint32_t)__builtin_popcountll(m2);
       }
       __syncthreads();
-      uint32_t cbase = sh_child_base[parity];
-      for (uint32_t q = 0; q < wv; q++) cbase += sh_children[parity][q];
+      uint32_t all_reflect = 0, all_refract = 0, before_reflect = 0, before_refract = 0;
+      for (uint32_t q = 0; q < 4; q++) {
+        if (q == wv) {
+          before_reflect = all_reflect;
+          before_refract = all_refract;
+        }
+        all_reflect += sh_children[parity][0][q];
+        all_refract += sh_children[parity][1][q];
+      }
+      if (threadIdx.x == 0) sh_child_base[parity] = all_reflect + all_refract ? atomicAdd(&w.ctrl->n_rays[level + 1], all_reflect + all_refract) : 0u;
+      __syncthreads();
+      const uint32_t cbase = sh_child_base[parity];
       parity ^= 1u;
-      store_children<STATS>(w, next, cbase, m1, m2, node, root, out, cnt);
+      store_children<STATS>(w, next, cbase + before_reflect, cbase + all_reflect + before_refract, m1, m2, node, root, out, cnt);
     }
     __syncthreads();  // sh_ids / sh_count / sh_base are rewritten by the next iteration
   }
