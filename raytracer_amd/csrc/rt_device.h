@@ -155,7 +155,8 @@ struct DevScene {
   const DevEntry* entries;    // reference-order path
   const uint4* prim_info;     // x shape, y material, z xform (RT_NONE = none), w geom (triangles: index in leaf order)
   const uint32_t* prim_csg_left;
-  const uint8_t* prim_flags;  // bit 0: the primitive's material has !approx_eq(transparency, 0) (intersection.rs:184-190)
+  const uint8_t* prim_flags;  // bit 0: the primitive's material has !approx_eq(transparency, 0) (intersection.rs:184-190) and the
+                              // scene has a refractive index other than 1.0: the container walk follows a closest hit on it
   const double* xform_inv;  // [n][16]
   const double* tri_isect;  // [n][RT_TRI_STRIDE]  p1, e1, e2, prim
   const double* tri_norm;   // [n][9]  n1, n2, n3
