@@ -37,7 +37,7 @@ enum { M_CLOSEST = 0, M_SHADOW = 1, M_CONTAINERS = 2 };
 
 // The set of modes a kernel's lanes can be in (bit m = mode m), so that a kernel which only ever traces shadow rays, or
 // never does, carries no code or registers for the other collectors.  MS_ALL: the mode is a per-lane run-time value.
-enum { MS_ALL = 7, MS_CLOSEST_CONTAINERS = 5, MS_SHADOW = 2 };
+enum { MS_ALL = 7, MS_CLOSEST_CONTAINERS = 5, MS_SHADOW = 2, MS_CLOSEST = 1 };
 
 // The ray being traversed and its collector (IntersectionCollector, intersection.rs:17-135, without the Vec).
 struct Trav {

@@ -467,6 +467,10 @@ __device__ __forceinline__ void flag_sample(const Ws& w, uint32_t root) {
 #define RT_LOAD_TOP_NODES(s) const uint4* lds_top = nullptr;
 #endif
 
+#ifndef RT_CLOSEST_WAVES_NO_WALK
+#define RT_CLOSEST_WAVES_NO_WALK 4  // the deeper levels' closest-hit kernel without the container walk, big batches: 124 VGPRs (level 0:
+                                    // 138, 3 waves).  4K frame 10.3 -> 10.1 ms; an 800x800 frame is slower with more, thinner wavefronts
+#endif
 #ifndef RT_CLOSEST_WAVES
 #define RT_CLOSEST_WAVES 3  // the closest-hit kernel also carries the container walk: 150 VGPRs (level 0) / 143 (deeper levels), no spills;
                             // 4 waves for the deeper levels (128 VGPRs, 12 spilled): 11.50 -> 11.63 ms.  Container walks as a kernel of
@@ -475,8 +479,10 @@ __device__ __forceinline__ void flag_sample(const Ws& w, uint32_t root) {
                             // 10.7 ms + walks 1.85 ms against 11.75 ms together — a walk is short (few boxes lie behind a ray's origin),
                             // pruning changes nothing, and what it costs is a ray's set-up, which the same lane doing both pays once
 #endif
-template <bool CAMERA, bool STATS, bool CSG, bool FIRST>
-__global__ __launch_bounds__(64, RT_CLOSEST_WAVES) void trace_closest_kernel(DevScene s, rt_camera cam, DevOptions opt, Ws w, Batch b,
+// WALK = false: for scenes in which no hit is followed by the container walk (DevScene::prim_flags all clear: no transparent
+// material, or every refractive index 1.0): the kernel carries no code or registers for it.
+template <bool CAMERA, bool STATS, bool CSG, bool FIRST, bool WALK = true, int WAVES = RT_CLOSEST_WAVES>
+__global__ __launch_bounds__(64, WAVES) void trace_closest_kernel(DevScene s, rt_camera cam, DevOptions opt, Ws w, Batch b,
                                                                           uint32_t level, unsigned long long* stats,
                                                                           uint32_t* overflow_flag) {
   __shared__ uint2 lds_stack[RT_LDS_STACK * 64];
@@ -532,10 +538,10 @@ __global__ __launch_bounds__(64, RT_CLOSEST_WAVES) void trace_closest_kernel(Dev
     }
     // ---- traverse; once the queue is dry there is nothing to refill with, so run to completion ----
     uint32_t min_active = __builtin_amdgcn_ballot_w64(exhausted && (threadIdx.x & 63u) < lanes) != 0ull ? 0u : (uint32_t)RT_REFILL_BELOW * lanes / 64u;
-    fast::trav_run<STATS, fast::MS_CLOSEST_CONTAINERS, CSG>(s, T, lds, ovf, cnt, min_active, lds_top);
+    fast::trav_run<STATS, WALK ? fast::MS_CLOSEST_CONTAINERS : fast::MS_CLOSEST, CSG>(s, T, lds, ovf, cnt, min_active, lds_top);
     // ---- lanes whose traversal is complete ----
     if (my != RT_NONE && !fast::trav_busy(T)) {
-      if (T.mode == fast::M_CLOSEST) {
+      if (!WALK || T.mode == fast::M_CLOSEST) {
         if (T.p == RT_NONE) {  // miss
           store_hit(w, level, my, RT_NONE, 0., 0., 0., 0., 0.);
           my = RT_NONE;
@@ -545,7 +551,7 @@ __global__ __launch_bounds__(64, RT_CLOSEST_WAVES) void trace_closest_kernel(Dev
           w.hit_f[my] = T.limit;  // (the ray's t slot: how far the retrace has to look, reforder::traverse's bound)
           my = RT_NONE;
         } else {
-          if (s.prim_flags[T.p] & 1u) {  // a transparent material (one byte instead of the prim_info -> material chain)
+          if (WALK && (s.prim_flags[T.p] & 1u)) {  // a transparent material (one byte instead of the prim_info -> material chain)
             // Intersection::compute_refractive (intersection.rs:184-190): the negative-t intersections of this ray
             ht = T.limit;
             hu = T.a;

@@ -488,6 +488,7 @@ struct rt_scene {
   uint32_t stack_need = 0;
   uint32_t n_lights = 0;
   bool has_csg = false;  // the scene holds CSG objects: the trace kernels built with their evaluation are launched
+  bool has_walks = true; // some primitive's closest hit is followed by the container walk (DevScene::prim_flags)
   int n_cus = 256;
   // workspace of the streamed pipeline: allocated at the first render, kept for the scene's lifetime, grown on demand
   mutable void* ws_base = nullptr;
@@ -1327,6 +1328,9 @@ struct TimedLaunch {  // records an event before and after one launch when the s
 #ifndef RT_SHADOW_SIDE_SAMPLES
 #define RT_SHADOW_SIDE_SAMPLES (64u << 20)
 #endif
+#ifndef RT_CLOSEST_BIG_SAMPLES
+#define RT_CLOSEST_BIG_SAMPLES (64u << 20)  // (rt_stream.h, RT_CLOSEST_WAVES_NO_WALK; a 1080p ss 4 batch of 33 M samples is no faster with it)
+#endif
 #ifndef RT_SHADE_BIG_SAMPLES
 #define RT_SHADE_BIG_SAMPLES (64u << 20)  // (rt_stream.h, RT_SHADE_SPAN_BIG)
 #endif
@@ -1337,7 +1341,7 @@ template <bool CAMERA, bool STATS>
 int run_stream_batch(const rt_scene* sc, const stream::Ws& w, const rt_camera& cam, const DevOptions& dopt, const stream::Batch& b,
                      hipStream_t st) {
   const uint32_t trace_grid = (uint32_t)sc->n_cus * 4u * RT_TRACE_WAVES, closest_grid = (uint32_t)sc->n_cus * 4u * RT_CLOSEST_WAVES;
-  const uint32_t wide_grid = (uint32_t)sc->n_cus * 8u;
+  const uint32_t wide_grid = (uint32_t)sc->n_cus * 8u, no_walk_grid = (uint32_t)sc->n_cus * 4u * RT_CLOSEST_WAVES_NO_WALK;
   uint32_t need = (b.n_samples + 255u) / 256u;
   const uint32_t first_grid = std::max(1u, std::min(wide_grid, need));
   // The shadow rays of level 0 (most of them) can run on the scene's side stream, beside the deeper levels' trace / shade
@@ -1362,15 +1366,21 @@ int run_stream_batch(const rt_scene* sc, const stream::Ws& w, const rt_camera& c
     {
       TimedLaunch t(sc, st, TC_TRACE_CLOSEST);
       // (the kernels without counters come in two builds: with and without the code for CSG objects)
-#define RT_LAUNCH_CLOSEST(ST, CSG, FIRST)                                                                                                \
-  hipLaunchKernelGGL((stream::trace_closest_kernel<CAMERA, ST, CSG, FIRST>), dim3(closest_grid), dim3(64), 0, st, sc->dev, cam, dopt, w, b, \
+#define RT_LAUNCH_CLOSEST(ST, CSG, FIRST, WALK)                                                                                                \
+  hipLaunchKernelGGL((stream::trace_closest_kernel<CAMERA, ST, CSG, FIRST, WALK>), dim3(closest_grid), dim3(64), 0, st, sc->dev, cam, dopt, w, b, \
                      level, sc->d_stats, sc->d_overflow)
       if (STATS || sc->has_csg) {
-        if (level == 0) RT_LAUNCH_CLOSEST(STATS, true, true);
-        else RT_LAUNCH_CLOSEST(STATS, true, false);
+        if (level == 0) RT_LAUNCH_CLOSEST(STATS, true, true, true);
+        else RT_LAUNCH_CLOSEST(STATS, true, false, true);
+      } else if (sc->has_walks) {
+        if (level == 0) RT_LAUNCH_CLOSEST(false, false, true, true);
+        else RT_LAUNCH_CLOSEST(false, false, false, true);
       } else {
-        if (level == 0) RT_LAUNCH_CLOSEST(false, false, true);
-        else RT_LAUNCH_CLOSEST(false, false, false);
+        if (level == 0) RT_LAUNCH_CLOSEST(false, false, true, false);
+        else if (b.n_samples >= RT_CLOSEST_BIG_SAMPLES)
+          hipLaunchKernelGGL((stream::trace_closest_kernel<CAMERA, false, false, false, false, RT_CLOSEST_WAVES_NO_WALK>), dim3(no_walk_grid), dim3(64), 0, st,
+                             sc->dev, cam, dopt, w, b, level, sc->d_stats, sc->d_overflow);
+        else RT_LAUNCH_CLOSEST(false, false, false, false);
       }
 #undef RT_LAUNCH_CLOSEST
     }
@@ -2041,6 +2051,7 @@ int rt_scene_create(const rt_scene_desc* d, rt_scene** out) try {
       double tr = d->material[(size_t)d->prim_material[i] * RT_MAT_STRIDE + RT_MAT_TRANSPARENCY];
       if (!(tr == 0. || std::fabs(tr - 0.) < 1.0e-8)) flags[i] = 1;  // !approx_eq(transparency, 0) (approx_eq.rs:16-20)
     }
+    sc->has_walks = std::find(flags.begin(), flags.end(), (uint8_t)1) != flags.end();
     UP(flags, prim_flags);
   }
   UPA(double, d->xform_inv, (size_t)d->n_xforms * 16, xform_inv);
