@@ -604,8 +604,7 @@ __global__ __launch_bounds__(64, 2) void retrace_kernel(DevScene s, rt_camera ca
     if (STATS) cnt.retraced++;
     double n1 = 1.0, n2 = 1.0;
     if (c.hit_prim != RT_NONE) {
-      uint32_t m = s.prim_info[c.hit_prim].y;
-      if (!approx_eq(s.material[(size_t)m * RT_MAT_STRIDE + RT_MAT_TRANSPARENCY], 0.)) {
+      if (s.prim_flags[c.hit_prim] & 1u) {  // a transparent material, in a scene where the walk's result is not known beforehand
         fast::Trav T;
         T.sp = 0;
         fast::trav_start(T, o, d, fast::M_CONTAINERS, 0.);
