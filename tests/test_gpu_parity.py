@@ -158,6 +158,37 @@ def test_lights_around_the_scene_one_to_ten():
         assert st["rays_shadow"] + st["rays_shadow_culled"] == st_ref["rays_shadow"] and (n == 1 or st["rays_shadow_culled"] > 0)
 
 
+@pytest.mark.parametrize("inner_index", [1.0, 1.5])
+def test_nested_glass_with_and_without_a_refractive_index(inner_index):
+    """The container walk behind a transparent closest hit (get_refractive, intersection.rs:258-302) is not made when every
+    material's refractive index is exactly 1.0 — its result is then (1.0, 1.0) whatever the ray meets —, and the closest-hit
+    kernels without its code are launched; one index of 1.5 anywhere brings the walk back.  Nested glass spheres in a
+    glass cube over a reflective floor, both ways, against the oracle and the reference-order render (which always walk)."""
+    sb = S.SceneBuilder()
+    clear = S.Material(S.Pattern(N.P_CONST, (0.1, 0.1, 0.2)), diffuse=0.3, specular=0., transparency=0.8, reflectivity=0.1,
+                       refractive_index=1.0)
+    inner = S.Material(S.Pattern(N.P_CONST, (0.2, 0.05, 0.05)), diffuse=0.2, transparency=0.7, reflectivity=0.3,
+                       refractive_index=inner_index)
+    sb.add_object(sb.primitive(N.CUBE, clear, S.matrix_from_transformations([S.Transformation.scaling(1.4, 1.4, 1.4)])))
+    sb.add_object(sb.primitive(N.SPHERE, clear, S.matrix_from_transformations([S.Transformation.scaling(1.1, 1.1, 1.1)])))
+    sb.add_object(sb.primitive(N.SPHERE, inner, S.matrix_from_transformations([S.Transformation.scaling(0.6, 0.6, 0.6)])))
+    sb.add_object(sb.primitive(N.SPHERE, S.Material(S.Pattern(N.P_CONST, (0.9, 0.8, 0.1))), S.matrix_from_transformations([
+        S.Transformation.scaling(0.25, 0.25, 0.25), S.Transformation.translation(0.1, 0., 0.)])))
+    sb.add_object(sb.primitive(N.PLANE, S.Material(S.Pattern(N.P_CONST, (0.5, 0.6, 0.5)), reflectivity=0.4), translation(0., -1.4, 0.)))
+    sb.add_light((-4., 6., -5.), (0.8, 0.8, 0.8))
+    sb.add_light((5., 3., -2.), (0.2, 0.2, 0.2))
+    cam = S.make_camera(72, 60, 1.0, S.view_transformation((0.6, 1.4, -5.), (0, 0, 0), (0, 1, 0)))
+    opt = S.make_options(supersampling_level=2, max_depth=5, shadow_intensity=True)
+    flat = sb.flatten()
+    gpu, st = R.render(flat, cam, opt)
+    check_against_oracle(flat, cam, opt, gpu=gpu)
+    ref, _ = R.render(flat, cam, _ref_order(opt))
+    assert float(np.abs(gpu - ref).max()) < 1e-12
+    plain, _ = R.render(flat, cam, opt, want_stats=False)  # the kernels without counters: the walk-free builds when inner_index == 1
+    assert np.array_equal(plain, gpu)
+    assert st["rays_refract"] > 0
+
+
 def test_two_primitive_csg_objects_of_every_kind():
     """fast::add_csg2 (a CSG object of two analytic primitives, at most two roots each, from one record): every operation over
     pairs of spheres, cubes, open cylinders and cones and planes at seeded random placements, glass and opaque, against the
