@@ -469,7 +469,8 @@ __device__ __forceinline__ void flag_sample(const Ws& w, uint32_t root) {
 
 #ifndef RT_CLOSEST_WAVES_NO_WALK
 #define RT_CLOSEST_WAVES_NO_WALK 4  // the deeper levels' closest-hit kernel without the container walk, big batches: 124 VGPRs (level 0:
-                                    // 138, 3 waves).  4K frame 10.3 -> 10.1 ms; an 800x800 frame is slower with more, thinner wavefronts
+                                    // 138, 3 waves; at 4 it spills 16: 10.05 -> 10.5 ms).  4K frame 10.3 -> 10.1 ms; an 800x800 frame is
+                                    // slower with more, thinner wavefronts
 #endif
 #ifndef RT_CLOSEST_WAVES
 #define RT_CLOSEST_WAVES 3  // the closest-hit kernel also carries the container walk: 150 VGPRs (level 0) / 143 (deeper levels), no spills;
