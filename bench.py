@@ -57,13 +57,22 @@ def unique_rays(st: dict) -> int:
 
 
 def cpu_model() -> str:
+    """Model name as /proc/cpuinfo gives it, plus family / model / stepping (a virtualised host may only say "AMD EPYC")."""
+    want = {"model name": None, "cpu family": None, "model": None, "stepping": None, "cpu MHz": None}
     try:
         for line in open("/proc/cpuinfo"):
-            if line.startswith("model name"):
-                return line.split(":", 1)[1].strip()
+            key, _, val = line.partition(":")
+            key = key.strip()
+            if key in want and want[key] is None:
+                want[key] = val.strip()
+            if all(v is not None for v in want.values()):
+                break
     except OSError:
         pass
-    return "unknown"
+    if want["model name"] is None:
+        return "unknown"
+    return (f'{want["model name"]} (family {want["cpu family"]} model {want["model"]} stepping {want["stepping"]}, '
+            f'{want["cpu MHz"]} MHz)')
 
 
 def cpu_baseline(flat, camera, options, budget_s: float = 15.0) -> dict:

@@ -19,7 +19,7 @@ impl Renderer {
             reference_order: 0,
             pipeline: 0,
             timing: 0,
-            n_devices: -1, // every visible GPU: the frame's tiles are dealt to them inside rt_render
+            n_devices: if image.width() * image.height() * n * n >= (1 << 24) { -1 } else { 1 }, // big frames: every visible GPU (tiles dealt inside rt_render); small ones: one
             progress: progressbar.as_ref().map(|_| bump_progress as unsafe extern "C" fn(u64, *mut std::ffi::c_void)),
             user: progressbar.as_ref().map_or(std::ptr::null_mut(), |pb| pb as *const indicatif::ProgressBar as *mut std::ffi::c_void),
         };

@@ -66,7 +66,9 @@ enum rt_status {
   RT_ERR_INVALID_ARGUMENT = -1, /* NULL where data is required, inconsistent counts, bad refs   */
   RT_ERR_UNSUPPORTED = -2,      /* scene exceeds a documented device limit      */
   RT_ERR_DEVICE = -3,           /* a HIP call failed, or no gfx950 device is usable             */
-  RT_ERR_OVERFLOW = -4,         /* a per-ray bounded list overflowed while rendering            */
+  RT_ERR_OVERFLOW = -4,         /* a per-ray bounded list overflowed while rendering: reported by rt_render and rt_trace_rays
+                                   always, by the device entry points only with stats != NULL (they are asynchronous
+                                   otherwise); rt_scene_create's limits make it unreachable for a scene it accepted */
   RT_ERR_HOST = -5              /* host memory or threads exhausted (no C++ exception ever leaves the library) */
 };
 
@@ -183,7 +185,8 @@ typedef struct rt_options {
   rt_progress_fn progress;   /* nullable.  Called with the number of pixels finished since the previous call (the unit of the
                                 reference's progress bar, image.rs:73: `progress_with(pb)` over the pixel iterator), from a thread
                                 of the HIP runtime, once per finished batch of tiles; the calls of one render sum to
-                                width * height.  Must not call back into this library */
+                                width * height.  With n_devices > 1 several runtime threads report; the library serialises the
+                                calls (one at a time, in any order).  Must not call back into this library */
   void* user;                /* passed to `progress` */
 } rt_options;
 #define RT_PIPELINE_STREAM 0u
@@ -252,6 +255,10 @@ void rt_scene_destroy(rt_scene* scene);
  * when an allocation fails; this call empties it on request. */
 void rt_release_cached_memory(void);
 
+/* Tears down what the library keeps for itself: waits for the current device, empties the pools above and
+ * the pinned staging blocks.  Scenes are the caller's to destroy first.  The library can be used again afterwards. */
+void rt_shutdown(void);
+
 /* Tile partition for multi-GPU frames: the image is cut into 8x8-pixel tiles in
  * row-major tile order; part p of n_parts owns the tiles with tile_id % n_parts == p.  The output
  * is PACKED: the k-th owned tile occupies d_out_rgb[k*64*3 .. (k+1)*64*3), pixel (tx,ty) of the tile
@@ -283,7 +290,11 @@ int rt_render_device(const rt_scene* scene, const rt_camera* camera, const rt_op
  * pipeline; options->reference_order and options->pipeline must be 0), but the ray queues, hit and node records, shadow
  * values and counters of the pipeline live in ONE static device array of RT_NOALLOC_SCRATCH_BYTES per GPU instead of a
  * workspace the library allocates, and the call makes no hipMalloc / hipFree / hipHostMalloc / hipEventCreate, nor
- * anything else that allocates: only kernel launches, hipMemsetAsync and one hipEventRecord on `hip_stream`.  A frame larger
+ * anything else that allocates: only kernel launches and hipMemsetAsync, ALL on `hip_stream` (the scene's side stream, which
+ * the allocating entry points use for small batches, is not used here), then one hipEventRecord of the scene's own event on
+ * `hip_stream`, which is what rt_scene_destroy waits for.  While `hip_stream` is being captured into a HIP graph
+ * (hipStreamIsCapturing) that event record is left out, and so is every synchronisation of the error paths: the caller then
+ * keeps the scene alive until the graph's launches have finished.  A frame larger
  * than the array is rendered in batches of 8x8 tiles; more than RT_NOALLOC_MAX_BATCHES batches (or a scene with so many
  * lights that one tile's batch does not fit) is refused with RT_ERR_UNSUPPORTED and a message giving the limit in
  * samples (about 90 000 samples per batch for a 2-light scene: 1200x1200 at supersampling 2 fits).  Every call on a GPU

@@ -162,6 +162,8 @@ def core_lib() -> C.CDLL:
     L.rt_scene_destroy.argtypes = [C.c_void_p]
     L.rt_release_cached_memory.argtypes = []
     L.rt_release_cached_memory.restype = None
+    L.rt_shutdown.argtypes = []
+    L.rt_shutdown.restype = None
     L.rt_tile_count.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]
     L.rt_tile_count.restype = C.c_uint32
     L.rt_render_tiles_device.argtypes = [C.c_void_p, cp, op, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, stp]

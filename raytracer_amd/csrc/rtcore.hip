@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstring>
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <memory>
 #include <mutex>
@@ -324,7 +325,7 @@ struct DevicePool {
   };
   std::mutex mu;
   std::vector<Block> blocks;  // oldest first
-  size_t cached = 0;
+  std::atomic<size_t> cached{0};  // (read without the mutex by ensure_workspace)
 
   // A block of at least `need` bytes on `device`: a cached one that is not more than twice too large, else a new one.
   void* take(size_t need, int device, size_t* cap) {
@@ -393,6 +394,7 @@ struct PinnedSlots {
     if (free_slots.empty()) {
       void* chunk = nullptr;
       if (hipHostMalloc(&chunk, 4096, hipHostMallocPortable) != hipSuccess) return nullptr;
+      chunks.push_back(chunk);
       for (size_t off = 0; off < 4096; off += 16) free_slots.push_back((uint32_t*)((char*)chunk + off));
     }
     uint32_t* s = free_slots.back();
@@ -403,6 +405,15 @@ struct PinnedSlots {
     if (!s) return;
     std::lock_guard<std::mutex> lock(mu);
     free_slots.push_back(s);
+  }
+  std::vector<void*> chunks;
+  // rt_shutdown: frees the chunks when no slot is out (a live scene still holds one: then they stay)
+  void release() {
+    std::lock_guard<std::mutex> lock(mu);
+    if (free_slots.size() != chunks.size() * (4096 / 16)) return;
+    for (void* c : chunks) (void)hipHostFree(c);
+    chunks.clear();
+    free_slots.clear();
   }
 };
 PinnedSlots g_pinned_slots;
@@ -512,6 +523,7 @@ struct rt_scene {
   ~rt_scene() {
     // the blocks go back to the pool, for other scenes to use at once: first wait for this scene's own GPU work
     if (rendered && done_event) (void)hipEventSynchronize(done_event);
+    if (side_stream) (void)hipStreamSynchronize(side_stream);  // (a batch that failed half-way may have left a shadow kernel there)
     if (summary_pending && summary_event) (void)hipEventSynchronize(summary_event);
     if (layout_learned) g_learned.remember(device, shape, nodes_per_sample, ratio_floor);
     g_device_pool.give(ws_base, ws_bytes, device);
@@ -1339,7 +1351,7 @@ struct TimedLaunch {  // records an event before and after one launch when the s
 #endif
 template <bool CAMERA, bool STATS>
 int run_stream_batch(const rt_scene* sc, const stream::Ws& w, const rt_camera& cam, const DevOptions& dopt, const stream::Batch& b,
-                     hipStream_t st) {
+                     hipStream_t st, bool allow_side = true) {
   const uint32_t trace_grid = (uint32_t)sc->n_cus * 4u * RT_TRACE_WAVES, closest_grid = (uint32_t)sc->n_cus * 4u * RT_CLOSEST_WAVES;
   const uint32_t wide_grid = (uint32_t)sc->n_cus * 8u, no_walk_grid = (uint32_t)sc->n_cus * 4u * RT_CLOSEST_WAVES_NO_WALK;
   uint32_t need = (b.n_samples + 255u) / 256u;
@@ -1352,7 +1364,7 @@ int run_stream_batch(const rt_scene* sc, const stream::Ws& w, const rt_camera& c
     const char* e = std::getenv("RT_SHADOW_SIDE_SAMPLES");
     return e ? std::strtoull(e, nullptr, 10) : (uint64_t)RT_SHADOW_SIDE_SAMPLES;
   }();
-  const bool use_side = RT_SHADOW_ON_SIDE_STREAM && dopt.max_depth > 0 && b.n_samples < side_below;
+  const bool use_side = RT_SHADOW_ON_SIDE_STREAM && allow_side && dopt.max_depth > 0 && b.n_samples < side_below;
   hipStream_t side = use_side ? sc->side_stream : st;
   auto launch_shadow = [&](uint32_t first, uint32_t last, hipStream_t on) {
     if (STATS || sc->has_csg)
@@ -1442,9 +1454,13 @@ struct ProgressCall {
   void* user;
   uint64_t pixels;
 };
+std::mutex g_progress_mu;  // n_devices > 1: one stream per device, so several runtime threads; the callback sees one call at a time
 void progress_trampoline(void* p) {
   ProgressCall* c = (ProgressCall*)p;
-  c->fn(c->pixels, c->user);
+  {
+    std::lock_guard<std::mutex> lock(g_progress_mu);
+    c->fn(c->pixels, c->user);
+  }
   delete c;
 }
 // Pixels (inside the image) of the tiles that part `part` of `n_parts` owns.
@@ -1488,7 +1504,7 @@ int post_progress(Progress* p, hipStream_t st, uint64_t pixels, bool last) {
 template <bool STATS>
 int stream_render_with(const rt_scene* sc, const stream::Ws& w, uint32_t batch_samples, const rt_camera* cam, const DevOptions& dopt,
                        uint32_t part, uint32_t n_parts, uint32_t tiles_x, uint32_t n_owned, int packed, double* d_out, hipStream_t st,
-                       Progress* progress = nullptr) {
+                       Progress* progress = nullptr, bool allow_side = true) {
   const uint32_t n2 = dopt.n_offsets * dopt.n_offsets, per_tile = 64u * n2;
   const uint32_t tiles_per_batch = std::max(1u, batch_samples / per_tile);
   if (tiles_per_batch * per_tile > batch_samples) return fail(RT_ERR_DEVICE, "render workspace smaller than one tile");
@@ -1508,7 +1524,7 @@ int stream_render_with(const rt_scene* sc, const stream::Ws& w, uint32_t batch_s
     b.n2_magic = (1ull << 32) / n2 + 1;
     hipLaunchKernelGGL(stream::tile_table_kernel, dim3(std::max(1u, std::min(1024u, (b.n_tiles + 255u) / 256u))), dim3(256), 0, st, b,
                        w.tile_xy);
-    int rc = run_stream_batch<true, STATS>(sc, w, *cam, dopt, b, st);
+    int rc = run_stream_batch<true, STATS>(sc, w, *cam, dopt, b, st, allow_side);
     if (rc) return rc;
     uint32_t grid = std::max(1u, std::min((uint32_t)sc->n_cus * 8u, (b.n_tiles * 64u + 255u) / 256u));
     {
@@ -1574,6 +1590,7 @@ int launch_render_once(const rt_scene* scene, const rt_camera* cam, const rt_opt
       scene->timing_on = false;
       if (rc) {
         (void)hipStreamSynchronize(stream);  // whatever was launched is over before the caller may destroy the scene
+        (void)hipStreamSynchronize(scene->side_stream);
         return rc;
       }
     }
@@ -1657,19 +1674,19 @@ std::vector<int> device_list(const rt_options* opt) {
   int cur = 0;
   (void)hipGetDevice(&cur);
   if (!opt || opt->n_devices == 0 || opt->n_devices == 1) return {cur};
-  if (const char* e = std::getenv("RT_DEVICE_LIST")) {
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || count < 1) return {cur};
+  if (const char* e = std::getenv("RT_DEVICE_LIST")) {  // (ids outside [0, count) are dropped)
     std::vector<int> v;
     for (const char* p = e; *p;) {
       char* end = nullptr;
       long d = std::strtol(p, &end, 10);
       if (end == p) break;
-      v.push_back((int)d);
+      if (d >= 0 && d < count) v.push_back((int)d);
       p = *end == ',' ? end + 1 : end;
     }
     if (!v.empty()) return v;
   }
-  int count = 0;
-  if (hipGetDeviceCount(&count) != hipSuccess || count < 1) return {cur};
   int n = opt->n_devices < 0 ? count : std::min(opt->n_devices, count);
   std::vector<int> v;
   for (int d = 0; d < n; d++) v.push_back(d);
@@ -1866,7 +1883,7 @@ int rt_scene_create(const rt_scene_desc* d, rt_scene** out) try {
   // The production tree is built on a second thread while this one lays out the reference-order records (both only read
   // the description; a third of a large scene's creation time each).  Small scenes are not worth a thread.
   FastLayout L;
-  bool layout_ok = true;
+  bool layout_ok = true, layout_threw = false;  // (declared before the thread that writes them: destroyed after it is joined)
   std::thread layout_thread;
   const bool two_threads = d->n_prims >= 4096;
   struct JoinOnExit {  // (every return below waits for it)
@@ -1875,7 +1892,6 @@ int rt_scene_create(const rt_scene_desc* d, rt_scene** out) try {
       if (t.joinable()) t.join();
     }
   } join_on_exit{layout_thread};
-  bool layout_threw = false;
   if (two_threads)
     layout_thread = std::thread([&] {
       try {
@@ -2111,6 +2127,13 @@ void rt_release_cached_memory(void) {
   g_download_stage.release();
 }
 
+void rt_shutdown(void) {
+  // (scenes are the caller's to destroy; what the library keeps for itself are the pools)
+  (void)hipDeviceSynchronize();
+  rt_release_cached_memory();
+  g_pinned_slots.release();
+}
+
 uint32_t rt_tile_count(uint32_t width, uint32_t height, uint32_t part, uint32_t n_parts) {
   if (n_parts == 0 || part >= n_parts) return 0;
   uint32_t n = tiles_total(width, height, nullptr);
@@ -2159,16 +2182,27 @@ int rt_render_device_noalloc(const rt_scene* scene, const rt_camera* camera, con
                                         " (RT_NOALLOC_MAX_BATCHES batches of the scratch array) are rendered for this scene and these options");
   const uint32_t batch_samples = (uint32_t)(lo * per_tile);
   carve_workspace(&w, base, batch_samples, ratio, scene->n_lights);
+  // Under stream capture nothing may synchronise and an event record would become a node of the graph: then the scene's
+  // done_event is left alone (the caller keeps the scene alive until the graph's launches have finished, include/rtcore.h).
+  hipStreamCaptureStatus capture = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(st, &capture) != hipSuccess) {
+    (void)hipGetLastError();
+    capture = hipStreamCaptureStatusNone;
+  }
+  const bool capturing = capture != hipStreamCaptureStatusNone;
   HIP_TRY(hipMemsetAsync(scene->d_overflow, 0, sizeof(uint32_t), st));
-  rc = stream_render_with<false>(scene, w, batch_samples, camera, dopt, 0, 1, tiles_x, n_tiles, 0, d_out_rgb, st);
+  // every kernel on the caller's stream (no side stream, no cross-stream events): allow_side = false
+  rc = stream_render_with<false>(scene, w, batch_samples, camera, dopt, 0, 1, tiles_x, n_tiles, 0, d_out_rgb, st, nullptr, false);
   if (rc) {
-    (void)hipStreamSynchronize(st);
+    if (!capturing) (void)hipStreamSynchronize(st);
     return rc;
   }
   // (the fallback kernel's frame summary is for the allocating entry points' layout heuristics: not carried over)
   HIP_TRY(hipMemsetAsync(scene->d_summary, 0, 3 * sizeof(uint32_t), st));
-  scene->rendered = true;
-  HIP_TRY(hipEventRecord(scene->done_event, st));
+  if (!capturing) {
+    scene->rendered = true;
+    HIP_TRY(hipEventRecord(scene->done_event, st));
+  }
   return RT_OK;
 } RT_NO_UNWIND
 
@@ -2295,6 +2329,11 @@ int rt_render(const rt_scene_desc* scene_desc, const rt_camera* camera, const rt
   if (rc == RT_OK || rc == RT_ERR_OVERFLOW) {
     if (stats) (void)hipEventRecord(e2.e, 0);
     if (download_image(out_rgb, image.p, bytes) != hipSuccess) rc = fail(RT_ERR_DEVICE, "download of the image failed");
+    if (!stats && rc == RT_OK) {  // (with stats launch_render has looked already; the download above has waited for the frame)
+      uint32_t ovf = 0;
+      if (hipMemcpy(&ovf, sc->d_overflow, sizeof(ovf), hipMemcpyDeviceToHost) == hipSuccess && ovf)
+        rc = fail(RT_ERR_OVERFLOW, "a per-ray bounded list (BVH stack or CSG hit list) overflowed on the device");
+    }
     if (stats) {
       (void)hipEventRecord(e3.e, 0);
       (void)hipEventSynchronize(e3.e);
