@@ -255,6 +255,13 @@ impl FlatScene {
             n_lights: (self.light_pos.len() / 3) as u32,
             light_pos: p(&self.light_pos),
             light_intensity: p(&self.light_intensity),
+            // no device-resident meshes in the plain `image` path (the animate path of hook.rs fills these)
+            n_meshes: 0,
+            mesh: std::ptr::null(),
+            mesh_bbox: std::ptr::null(),
+            mesh_built: std::ptr::null(),
+            mesh_material_begin: std::ptr::null(),
+            mesh_material: std::ptr::null(),
         }
     }
 }

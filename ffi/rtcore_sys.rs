@@ -1,13 +1,14 @@
-//! `#[repr(C)]` mirror of include/rtcore.h, ABI version 2.  Field order and types follow the header exactly;
+//! `#[repr(C)]` mirror of include/rtcore.h, ABI version 3.  Field order and types follow the header exactly;
 //! tests/test_capi.py checks the same layout for the ctypes mirror against a C compiler.
 #![allow(non_camel_case_types)]
 use std::os::raw::{c_char, c_void};
 
-pub const RT_ABI_VERSION: u32 = 2;
+pub const RT_ABI_VERSION: u32 = 3;
 pub const RT_NONE: u32 = 0xFFFF_FFFF;
 pub const RT_REF_NODE: u32 = 0;
 pub const RT_REF_PRIM: u32 = 1;
 pub const RT_REF_CSG: u32 = 2;
+pub const RT_REF_MESH: u32 = 3;
 pub const fn rt_make_ref(kind: u32, index: u32) -> u32 {
     (kind << 30) | (index & 0x3FFF_FFFF)
 }
@@ -53,6 +54,32 @@ pub struct rt_scene_desc {
     pub n_lights: u32,
     pub light_pos: *const f64,
     pub light_intensity: *const f64,
+    pub n_meshes: u32,
+    pub mesh: *const *mut rt_mesh,
+    pub mesh_bbox: *const f64,
+    pub mesh_built: *const u8,
+    pub mesh_material_begin: *const u32,
+    pub mesh_material: *const u32,
+}
+
+#[repr(C)]
+pub struct rt_mesh {
+    _opaque: [u8; 0],
+}
+
+#[repr(C)]
+pub struct rt_mesh_desc {
+    pub n_tris: u32,
+    pub shape: *const u8,
+    pub p1: *const f64,
+    pub p2: *const f64,
+    pub p3: *const f64,
+    pub n1: *const f64,
+    pub n2: *const f64,
+    pub n3: *const f64,
+    pub bbox: *const f64,
+    pub material: *const u32,
+    pub n_palette: u32,
 }
 
 #[repr(C)]
@@ -92,4 +119,9 @@ extern "C" {
     pub fn rt_render_device(scene: *const c_void, camera: *const rt_camera, options: *const rt_options,
                             d_out_rgb: *mut c_void, hip_stream: *mut c_void, stats: *mut c_void) -> i32;
     pub fn rt_quantize_device(d_rgb: *const f64, n_values: u64, d_out_u8: *mut u8, hip_stream: *mut c_void) -> i32;
+    // device-side per-frame scene preparation (animated triangle groups): see include/rtcore.h
+    pub fn rt_mesh_create(desc: *const rt_mesh_desc, out: *mut *mut rt_mesh) -> i32;
+    pub fn rt_mesh_destroy(mesh: *mut rt_mesh);
+    pub fn rt_mesh_pose(mesh: *mut rt_mesh, n_matrices: u32, matrices: *const f64, out_bbox6: *mut f64) -> i32;
+    pub fn rt_shutdown();
 }

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define RT_ABI_VERSION 2u
+#define RT_ABI_VERSION 3u
 
 /* ---- child references --------------------------------------------------------------------- */
 /* A child reference packs the kind of an `Object` (src/scene/object.rs:26-30) in bits 31..30   */
@@ -33,6 +33,8 @@ extern "C" {
 #define RT_REF_NODE 0u /* ObjectKind::Group  -> index into the node tables  */
 #define RT_REF_PRIM 1u /* ObjectKind::Primitive -> index into the prim tables */
 #define RT_REF_CSG  2u /* ObjectKind::Csg    -> index into the csg tables   */
+#define RT_REF_MESH 3u /* ObjectKind::Group whose children are all triangle primitives and live on the device
+                          (rt_mesh below) -> index into rt_scene_desc::mesh */
 #define RT_MAKE_REF(kind, index) (((uint32_t)(kind) << RT_REF_KIND_SHIFT) | ((uint32_t)(index) & RT_REF_INDEX_MASK))
 #define RT_NONE 0xFFFFFFFFu
 
@@ -148,6 +150,20 @@ typedef struct rt_scene_desc {
   uint32_t n_lights;
   const double* light_pos;       /* [n_lights][3] */
   const double* light_intensity; /* [n_lights][3] */
+
+  /* device-resident triangle groups (rt_mesh, below), referenced from child_ref as RT_MAKE_REF(RT_REF_MESH, k): the group's
+   * children are NOT in the tables above; rt_scene_create transforms nothing (rt_mesh_pose has) and, on the device, builds the
+   * subtree ObjectGroup::build_bvh (group.rs:144-167) makes of that group.  0 meshes: everything as before. */
+  uint32_t n_meshes;
+  struct rt_mesh* const* mesh;         /* [n_meshes] posed meshes, each referenced exactly once, outside CSG objects */
+  const double* mesh_bbox;             /* [n_meshes][6] the group's ObjectGroup::bounding_box as the host's tree holds it: after
+                                          Scene::animate that is the union rt_mesh_pose returned (group.rs:230-241); on the
+                                          `image` path whatever the group's own transforms left (group.rs:263-270 transforms
+                                          the box by its corners).  It positions the candidate planes of the group's first split */
+  const uint8_t* mesh_built;           /* [n_meshes] 1: build_bvh reached this group (every ancestor has at most two children
+                                          after the build, group.rs:145-156); 0: it keeps its flat child list */
+  const uint32_t* mesh_material_begin; /* [n_meshes + 1] into mesh_material */
+  const uint32_t* mesh_material;       /* palette entry p of mesh k -> index into this scene's material tables */
 } rt_scene_desc;
 
 /* `Camera` (src/scene/camera.rs:9-18); the three derived scalars are computed by the caller exactly
@@ -247,6 +263,49 @@ typedef struct rt_scene rt_scene; /* opaque: the scene re-laid-out in device mem
  * "hand a flattened scene to the kernels" step of the north star. */
 int rt_scene_create(const rt_scene_desc* scene, rt_scene** out);
 void rt_scene_destroy(rt_scene* scene);
+
+/* ---- device-side per-frame scene preparation -------------------------------
+ * An animation renders frame i from Scene::animate(time) = clone + animate + compute_bvh (scene.rs:30-36,
+ * animation_renderer.rs:61-66): every frame the host transforms every triangle of an animated model
+ * (PrimitiveObject::transform, object.rs:454-472) and rebuilds the tree over them (ObjectGroup::build_bvh, group.rs:87-167).
+ * An rt_mesh keeps such a group — one whose children are all triangle primitives without a transformation of their own: what
+ * obj_model.rs makes of an OBJ file or of one of its `g` groups — on the device, and both steps run there:
+ *   rt_mesh_create   once: the triangles as the scene holds them BEFORE any animation (the clone's starting point).
+ *   rt_mesh_pose     per frame: Object::transform(m_0), ..., transform(m_{k-1}) applied to every triangle in this order from
+ *                    the base pose — the matrices the group received on its way down Object::animate (object.rs:108-121,
+ *                    group.rs:242-247, 263-270), in the reference's per-vertex operation order (triangle.rs:24-47,
+ *                    smooth_triangle.rs:29-55; boxes by their 8 corners, bounding_box.rs:47-63) — and the group's
+ *                    recalculate_bbox (group.rs:230-235) handed back, which the caller's own (small) tree above needs.
+ *   rt_scene_create  with the mesh referenced from the scene's tree (RT_REF_MESH): builds the reference's subtree of the
+ *                    group on the device, bit for bit the tree build_bvh builds (same candidate planes, same strict
+ *                    comparisons, stable partitions), and lays it out for the kernels.
+ * A posed mesh belongs to ONE scene at a time: pose, create the scene, and only then pose for the next frame (the scene has
+ * its own copy of everything by then).  Not thread-safe per mesh. */
+typedef struct rt_mesh rt_mesh;
+typedef struct rt_mesh_desc {
+  uint32_t n_tris;
+  const uint8_t* shape;     /* [n_tris] RT_SHAPE_TRIANGLE or RT_SHAPE_SMOOTH_TRIANGLE */
+  const double* p1;         /* [n_tris][3] Triangle::p1/p2/p3 (triangle.rs:10-17; e1, e2 and a flat normal are derived) */
+  const double* p2;
+  const double* p3;
+  const double* n1;         /* [n_tris][3] SmoothTriangle::n1/n2/n3 (ignored for flat triangles; may be NULL without smooth ones) */
+  const double* n2;
+  const double* n3;
+  const double* bbox;       /* [n_tris][6] PrimitiveObject::bbox (object.rs:362): it is transformed by its corners, not recomputed */
+  const uint32_t* material; /* [n_tris] palette entry of each triangle's material, < n_palette */
+  uint32_t n_palette;
+} rt_mesh_desc;
+#define RT_MESH_MAX_MATRICES 8u
+int rt_mesh_create(const rt_mesh_desc* desc, rt_mesh** out);
+void rt_mesh_destroy(rt_mesh* mesh);
+/* matrices: [n_matrices][16] row-major, n_matrices <= RT_MESH_MAX_MATRICES (0: the base pose); out_bbox6: min xyz, max xyz.
+ * Synchronous (it returns the box). */
+int rt_mesh_pose(rt_mesh* mesh, uint32_t n_matrices, const double* matrices, double* out_bbox6);
+
+/* Debugging / tests: copies one of a scene's device tables to the host.  which: 0 tri_isect, 1 tri_norm, 2 prim_rank,
+ * 3 prim_info, 4 entries, 5 nodes, 6 prim_flags.  Returns the table's size in bytes (negative rt_status on error); copies
+ * min(size, capacity) bytes. */
+long long rt_scene_debug_table(const rt_scene* scene, int which, void* out, unsigned long long capacity);
 
 /* Library housekeeping, no counterpart in the reference.  Destroyed scenes leave their device blocks (table arena,
  * render workspace) in a process-wide pool for the next rt_scene_create / render on the same device: an animation makes

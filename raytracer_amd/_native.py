@@ -12,9 +12,9 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_DIR = os.path.join(_HERE, "lib")
 
-RT_ABI_VERSION = 2
+RT_ABI_VERSION = 3
 RT_NONE = 0xFFFFFFFF
-RT_REF_NODE, RT_REF_PRIM, RT_REF_CSG = 0, 1, 2
+RT_REF_NODE, RT_REF_PRIM, RT_REF_CSG, RT_REF_MESH = 0, 1, 2, 3
 RT_TILE_DIM = 8
 RT_MAX_DEPTH = 16
 
@@ -45,7 +45,14 @@ class rt_scene_desc(C.Structure):
         ("n_materials", C.c_uint32), ("material", _pd), ("pattern_kind", _pu8), ("pattern_c1", _pd), ("pattern_c2", _pd),
         ("pattern_inv", _pd),
         ("n_lights", C.c_uint32), ("light_pos", _pd), ("light_intensity", _pd),
+        ("n_meshes", C.c_uint32), ("mesh", C.POINTER(C.c_void_p)), ("mesh_bbox", _pd), ("mesh_built", _pu8), ("mesh_material_begin", _pu32),
+        ("mesh_material", _pu32),
     ]
+
+
+class rt_mesh_desc(C.Structure):
+    _fields_ = [("n_tris", C.c_uint32), ("shape", _pu8), ("p1", _pd), ("p2", _pd), ("p3", _pd), ("n1", _pd), ("n2", _pd),
+                ("n3", _pd), ("bbox", _pd), ("material", _pu32), ("n_palette", C.c_uint32)]
 
 
 class rt_camera(C.Structure):
@@ -140,6 +147,8 @@ def scene_lib() -> C.CDLL:
     L.rts_flatten.argtypes = [C.c_void_p, C.c_double, C.c_int, C.POINTER(rt_scene_desc)]
     L.rts_flatten_frame.argtypes = [C.c_void_p, C.c_double, C.c_int, C.POINTER(C.c_void_p), C.POINTER(rt_scene_desc)]
     L.rts_frame_free.argtypes = [C.c_void_p]
+    L.rts_extract_meshes.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.rts_mesh_count.argtypes = [C.c_void_p]
     _scene_lib = L
     return L
 
@@ -162,6 +171,12 @@ def core_lib() -> C.CDLL:
     L.rt_scene_destroy.argtypes = [C.c_void_p]
     L.rt_release_cached_memory.argtypes = []
     L.rt_release_cached_memory.restype = None
+    L.rt_mesh_create.argtypes = [C.POINTER(rt_mesh_desc), C.POINTER(C.c_void_p)]
+    L.rt_mesh_destroy.argtypes = [C.c_void_p]
+    L.rt_mesh_destroy.restype = None
+    L.rt_mesh_pose.argtypes = [C.c_void_p, C.c_uint32, _pd, _pd]
+    L.rt_scene_debug_table.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_ulonglong]
+    L.rt_scene_debug_table.restype = C.c_longlong
     L.rt_shutdown.argtypes = []
     L.rt_shutdown.restype = None
     L.rt_tile_count.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]

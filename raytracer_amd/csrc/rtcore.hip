@@ -93,6 +93,7 @@ __device__ __forceinline__ uint32_t blocked_order(uint32_t j, uint32_t gx, uint3
 }
 
 #include "rt_stream.h"  // the production pipeline (uses flush_counters and blocked_order above)
+#include "rt_mesh.h"    // device-side per-frame scene preparation (rt_mesh_*; rt_scene_create with RT_REF_MESH children)
 
 // Renderer::color_at_pixel (renderer.rs:50-66) for one 8x8 tile per wavefront, the whole recursion in one kernel.
 // REFORDER = false: the single-kernel core (rt_fast.h; rt_options.pipeline = 1, and the fallback of the streamed
@@ -478,6 +479,31 @@ struct LearnedLayout {
 };
 LearnedLayout g_learned;
 
+// A group of triangle primitives resident on the device (include/rtcore.h "rt_mesh"; kernels in rt_mesh.h).
+struct rt_mesh {
+  int device = 0;
+  uint32_t n = 0, n_palette = 0;
+  void* block = nullptr;  // base pose, frame pose and build state: one allocation
+  size_t block_bytes = 0;
+  mesh::MeshDev dev{};
+  hipStream_t stream = nullptr;
+  unsigned long long* h_box = nullptr;  // pinned: the posed group's box as keys, then a copy of the build's Ctrl
+  mesh::Ctrl* h_ctrl = nullptr;
+  bool posed = false;
+  bool acc_clean = false;     // every accumulator is empty (true after a complete build)
+  uint32_t last_levels = 0;   // levels of the previous frame's tree: how many to launch before looking
+  uint32_t cur = 0;           // which order buffer holds the finished order
+  double bbox[6] = {};
+  ~rt_mesh() {
+    if (stream) {
+      (void)hipStreamSynchronize(stream);
+      (void)hipStreamDestroy(stream);
+    }
+    if (block) (void)hipFree(block);
+    if (h_box) (void)hipHostFree(h_box);
+  }
+};
+
 struct rt_scene {
   DevScene dev;
   // every scene table, the statistics counters and the summary word live in ONE device block (rt_scene_create)
@@ -485,6 +511,10 @@ struct rt_scene {
   size_t arena_cap = 0;
   struct StageBuffer* stage = nullptr;             // while rt_scene_create runs: the arena's contents on the host
   std::vector<std::pair<size_t, void*>> fixups;    // (offset in the arena, address of the device pointer to set)
+  std::vector<std::pair<size_t, size_t>> reserved; // [begin, end) of the arena image that the DEVICE fills (mesh parts of tables): not uploaded
+  const uint32_t* mesh_mat_map = nullptr;          // the meshes' palettes as this scene's material indices / flags (rt_mesh.h MeshOut)
+  const uint8_t* mesh_mat_flags = nullptr;
+  size_t table_bytes[7] = {};                      // rt_scene_debug_table: tri_isect, tri_norm, prim_rank, prim_info, entries, nodes, prim_flags
   int device = 0;
   void* noalloc_scratch = nullptr;          // this device's copy of the `scratch` array (rt_render_device_noalloc)
   mutable hipEvent_t done_event = nullptr;  // recorded after every render: what the destructor waits for
@@ -548,20 +578,22 @@ namespace {
 // (the image is built in a buffer that the thread keeps: a fresh 50-MB vector costs more in page faults, ~20 ms, than
 // filling and copying it)
 thread_local StageBuffer t_stage;
-size_t stage_bytes(rt_scene* sc, const void* data, size_t bytes, void* pointer_to_set) {
+// tail: bytes behind the table that the device fills (the mesh parts, rt_mesh.h): part of the table, not of the upload.
+size_t stage_bytes(rt_scene* sc, const void* data, size_t bytes, void* pointer_to_set, size_t tail = 0) {
   StageBuffer& st = *sc->stage;
   size_t off = (st.size + 255) & ~(size_t)255, len = std::max<size_t>(bytes, 16);
-  char* p = st.resize(off + len);
+  char* p = st.resize(off + std::max(len, bytes + tail));
   if (!p) return 0;  // commit_arena reports it
   if (bytes && data) std::memcpy(p + off, data, bytes);
   else std::memset(p + off, 0, len);  // no data: zeros
+  if (tail) sc->reserved.push_back({off + bytes, off + bytes + tail});  // (element `bytes / sizeof(T)` of the table is the tail's first)
   sc->fixups.push_back({off, pointer_to_set});
-  sc->bytes += bytes;
+  sc->bytes += bytes + tail;
   return off;
 }
 template <class T>
-int upload(rt_scene* sc, const std::vector<T>& host, const T** out) {
-  stage_bytes(sc, host.data(), host.size() * sizeof(T), (void*)out);
+int upload(rt_scene* sc, const std::vector<T>& host, const T** out, size_t tail_elements = 0) {
+  stage_bytes(sc, host.data(), host.size() * sizeof(T), (void*)out, tail_elements * sizeof(T));
   return RT_OK;
 }
 // One device block for everything staged, one copy (on a stream of its own: a copy on the null stream would wait for, and
@@ -575,7 +607,14 @@ int commit_arena(rt_scene* sc) {
   hipStream_t up = nullptr;
   HIP_TRY(hipStreamCreateWithFlags(&up, hipStreamNonBlocking));
   auto t0 = std::chrono::steady_clock::now();
-  hipError_t e = hipMemcpyWithStream(sc->arena, st.p, st.size, hipMemcpyHostToDevice, up);
+  // everything but the ranges the device fills itself
+  hipError_t e = hipSuccess;
+  size_t at = 0;
+  for (size_t r = 0; r <= sc->reserved.size() && e == hipSuccess; r++) {
+    const size_t end = r < sc->reserved.size() ? sc->reserved[r].first : st.size;
+    if (end > at) e = hipMemcpyWithStream((char*)sc->arena + at, st.p + at, end - at, hipMemcpyHostToDevice, up);
+    if (r < sc->reserved.size()) at = sc->reserved[r].second;
+  }
   if (e == hipSuccess) e = hipStreamSynchronize(up);
   if (std::getenv("RT_DEBUG_TIMING"))
     fprintf(stderr, "[rtcore] arena copy %zu bytes: %.2f ms\n", st.size,
@@ -589,6 +628,7 @@ int commit_arena(rt_scene* sc) {
   st.size = 0;  // capacity kept
   sc->stage = nullptr;
   sc->fixups.clear();
+  sc->reserved.clear();
   return RT_OK;
 }
 
@@ -597,21 +637,32 @@ bool ref_ok(const rt_scene_desc* d, uint32_t ref) {
   if (kind == RT_REF_NODE) return idx < d->n_nodes;
   if (kind == RT_REF_PRIM) return idx < d->n_prims;
   if (kind == RT_REF_CSG) return idx < d->n_csgs;
+  if (kind == RT_REF_MESH) return idx < d->n_meshes;
   return false;
 }
 
+// Stack entries of the reference-order walk (rt_reforder.h) a mesh's own tree can hold, by mesh: known once the device has
+// built it (0 before: rt_scene_create checks the rest of the scene first and the whole again afterwards).
+struct MeshNeeds {
+  std::vector<uint32_t> sub;  // [n_meshes]
+};
+
 // Worst-case traversal stack (group.rs:176-199): while child i of a node is being processed, its later
 // group siblings are still on the stack.
-uint32_t stack_need(const rt_scene_desc* d, uint32_t node, std::vector<int64_t>& memo, int guard) {
+uint32_t stack_need(const rt_scene_desc* d, uint32_t node, std::vector<int64_t>& memo, int guard, const MeshNeeds* meshes = nullptr) {
   if (memo[node] >= 0) return (uint32_t)memo[node];
   if (guard > 100000) return 1u << 30;
   uint32_t b = d->node_child_begin[node], e = d->node_child_begin[node + 1];
-  std::vector<uint32_t> groups;
-  for (uint32_t i = b; i < e; i++)
-    if ((d->child_ref[i] >> RT_REF_KIND_SHIFT) == RT_REF_NODE) groups.push_back(d->child_ref[i] & RT_REF_INDEX_MASK);
+  std::vector<uint32_t> groups;  // (child references: groups and meshes, which the walk enters like groups)
+  for (uint32_t i = b; i < e; i++) {
+    const uint32_t kind = d->child_ref[i] >> RT_REF_KIND_SHIFT;
+    if (kind == RT_REF_NODE || kind == RT_REF_MESH) groups.push_back(d->child_ref[i]);
+  }
   uint32_t k = (uint32_t)groups.size(), need = k;
   for (uint32_t i = 0; i < k; i++) {
-    uint32_t sub = stack_need(d, groups[i], memo, guard + 1);
+    uint32_t sub = (groups[i] >> RT_REF_KIND_SHIFT) == RT_REF_MESH
+                       ? (meshes ? meshes->sub[groups[i] & RT_REF_INDEX_MASK] : 0u)
+                       : stack_need(d, groups[i] & RT_REF_INDEX_MASK, memo, guard + 1, meshes);
     uint32_t v = (k - 1 - i) + sub;
     if (v > need) need = v;
   }
@@ -635,6 +686,8 @@ struct FastLayout {
   std::vector<uint32_t> prim_rank;
   std::vector<uint32_t> prim_tri;  // triangle primitives: slot in the device triangle tables (leaf order), else RT_NONE
   uint32_t n_dev_tris = 0;
+  std::vector<uint32_t> mesh_rank0;  // [n_meshes] visit rank of each mesh's first-visited triangle (assign_ranks)
+  std::vector<uint32_t> mesh_held;   // [n_meshes] stack entries held when the mesh's root node is visited (fold_nodes)
   uint32_t depth = 0;
   uint32_t leaf_tris = 2;      // all-triangle subtrees of at most this many triangles are one leaf (<= 2: the reference's own
                                // leaves).  4 was best while a node step cost 30 instructions per box (r01: dragons 4K 54.5 ->
@@ -708,6 +761,11 @@ void set_node_box(DevNode& n, int child, const double* bb) {
 }
 #endif
 
+// In the layout passes a mesh child stands as this reference (kind EMPTY, never RT_FREF_NONE); rt_scene_create replaces it by
+// the mesh's root node once the node table's size is known.
+#define RT_MESH_MARKER(k) RT_MAKE_FREF(RT_FREF_EMPTY, 1u, (k))
+#define RT_IS_MESH_MARKER(r) ((r) != RT_FREF_NONE && ((r) >> RT_FREF_KIND_SHIFT) == RT_FREF_EMPTY)
+
 struct FastItem {  // how a parent refers to one child: reference + the box tested before entering it
   uint32_t ref;
   double bb[6];
@@ -721,19 +779,31 @@ bool is_triangle_prim(const rt_scene_desc* d, uint32_t prim) {
 // Visit order of ObjectGroup::intersect_iter (group.rs:171-201): a popped group handles its children in reverse,
 // primitives and CSG objects at once, sub-groups pushed (so they pop in forward order).  Every leaf primitive of a
 // CSG object shares the CSG's rank (its survivors reach the collector in one push sequence, csg.rs:119-121).
-void assign_ranks(const rt_scene_desc* d, std::vector<uint32_t>& rank) {
+// A mesh (RT_REF_MESH) is a group: it is pushed like one, and when it pops its triangles take the next n ranks (in which
+// order among themselves: rt_mesh.h finalize_kernel).
+uint32_t mesh_tris(const rt_scene_desc* d, uint32_t k);
+void assign_ranks(const rt_scene_desc* d, std::vector<uint32_t>& rank, std::vector<uint32_t>& mesh_rank0) {
   rank.assign(d->n_prims, 0xFFFFFFFFu);
+  mesh_rank0.assign(d->n_meshes, 0u);
   uint32_t next = 0;
-  std::vector<uint32_t> stack{0};
+  std::vector<uint32_t> stack{0};  // group indices; bit 31: a mesh
   std::vector<uint32_t> csg_stack;
   while (!stack.empty()) {
     uint32_t g = stack.back();
     stack.pop_back();
+    if (g & 0x80000000u) {
+      const uint32_t k = g & 0x7FFFFFFFu;
+      mesh_rank0[k] = next;
+      next += mesh_tris(d, k);
+      continue;
+    }
     uint32_t b = d->node_child_begin[g], e = d->node_child_begin[g + 1];
     for (uint32_t i = e; i-- > b;) {
       uint32_t ref = d->child_ref[i], kind = ref >> RT_REF_KIND_SHIFT, idx = ref & RT_REF_INDEX_MASK;
       if (kind == RT_REF_NODE) {
         stack.push_back(idx);
+      } else if (kind == RT_REF_MESH) {
+        stack.push_back(idx | 0x80000000u);
       } else if (kind == RT_REF_PRIM) {
         rank[idx] = next++;
       } else {
@@ -874,16 +944,22 @@ uint32_t build_group(const rt_scene_desc* d, FastLayout& L, uint32_t g, uint32_t
   }
   RefList direct, groups;
   for (uint32_t i = b; i < e; i++) {
-    uint32_t ref = d->child_ref[i];
-    if ((ref >> RT_REF_KIND_SHIFT) == RT_REF_NODE) groups.push_back(ref & RT_REF_INDEX_MASK);
+    uint32_t ref = d->child_ref[i], kind = ref >> RT_REF_KIND_SHIFT;
+    if (kind == RT_REF_NODE || kind == RT_REF_MESH) groups.push_back(ref);
     else direct.push_back(ref);
   }
   ItemList items;
   make_leaves(d, L, direct, bb, items);
   if (groups.empty() && items.size() == 1) return items[0].ref;  // a plain leaf group: no node of its own
   for (size_t gi = 0; gi < groups.size(); gi++) {
-    const uint32_t c = groups[gi];
+    const uint32_t c = groups[gi] & RT_REF_INDEX_MASK;
     FastItem it;
+    if ((groups[gi] >> RT_REF_KIND_SHIFT) == RT_REF_MESH) {  // its subtree is built on the device: a marker, resolved after the fold
+      std::memcpy(it.bb, d->mesh_bbox + (size_t)c * 6, sizeof(it.bb));
+      it.ref = RT_MESH_MARKER(c);
+      items.push_back(it);
+      continue;
+    }
     std::memcpy(it.bb, d->node_bbox + (size_t)c * 6, sizeof(it.bb));
     it.ref = build_group(d, L, c, depth + 1);
     if (!L.error.empty()) return RT_FREF_NONE;
@@ -979,14 +1055,18 @@ void fold_nodes(FastLayout& L) {
         todo.push_back({slots[i].ref & RT_FREF_INDEX_MASK, wide, held});
       } else {
         n.ref[i] = slots[i].ref;
+        if (RT_IS_MESH_MARKER(slots[i].ref)) L.mesh_held[slots[i].ref & RT_FREF_INDEX_MASK] = held;
       }
     }
     L.nodes[t.wide] = n;
   }
 }
 
+uint32_t mesh_tris(const rt_scene_desc* d, uint32_t k) { return d->mesh[k]->n; }
+
 bool build_fast_layout(const rt_scene_desc* d, FastLayout& L) {
-  assign_ranks(d, L.prim_rank);
+  assign_ranks(d, L.prim_rank, L.mesh_rank0);
+  L.mesh_held.assign(d->n_meshes, 0u);
   L.prim_tri.assign(d->n_prims, RT_NONE);
   if (const char* e = getenv("RT_LEAF_TRIS")) L.leaf_tris = (uint32_t)std::min(std::max(atoi(e), 1), (int)RT_FREF_LEAF_MAX);
   L.bin.reserve((size_t)d->n_nodes + 2);
@@ -1036,6 +1116,7 @@ uint32_t max_roots(const rt_scene_desc* d, uint32_t prim) {
 int check_graph(const rt_scene_desc* d) {
   const uint32_t N = d->n_nodes, C = d->n_csgs;
   std::vector<uint8_t> seen(N + C, 0);  // 0 not visited, 1 on the current path, 2 done
+  std::vector<uint8_t> mesh_seen(d->n_meshes, 0);
   struct Frame {
     uint32_t v, next, csg_depth;
     bool in_csg, in_csg_group;
@@ -1063,6 +1144,11 @@ int check_graph(const rt_scene_desc* d) {
       if (f.in_csg) f.roots += max_roots(d, idx);
       continue;
     }
+    if (kind == RT_REF_MESH) {
+      if (f.in_csg) return fail(RT_ERR_UNSUPPORTED, "a device-resident mesh inside a CSG object is not supported");
+      if (mesh_seen[idx]++) return fail(RT_ERR_INVALID_ARGUMENT, "a mesh is referenced more than once");
+      continue;
+    }
     uint32_t u = kind == RT_REF_NODE ? idx : N + idx;
     if (seen[u] == 1) return fail(RT_ERR_INVALID_ARGUMENT, "the object graph has a cycle (a group or CSG object contains itself)");
     if (seen[u] == 2) return fail(RT_ERR_INVALID_ARGUMENT, "a group or CSG object is referenced more than once");
@@ -1080,6 +1166,8 @@ int check_graph(const rt_scene_desc* d) {
     seen[u] = 1;
     path.push_back(g);  // (f is dangling from here on)
   }
+  for (uint32_t k = 0; k < d->n_meshes; k++)
+    if (!mesh_seen[k]) return fail(RT_ERR_INVALID_ARGUMENT, "a mesh of rt_scene_desc::mesh is not referenced from the scene's tree");
   return RT_OK;
 }
 
@@ -1097,7 +1185,7 @@ int validate(const rt_scene_desc* d) {
     if (!ref_ok(d, d->child_ref[i])) return fail(RT_ERR_INVALID_ARGUMENT, "child_ref out of range");
   if (d->n_prims && (!d->prim_shape || !d->prim_material || !d->prim_xform || !d->prim_geom || !d->prim_csg_left))
     return fail(RT_ERR_INVALID_ARGUMENT, "primitive tables missing");
-  if (d->n_materials == 0 && d->n_prims) return fail(RT_ERR_INVALID_ARGUMENT, "no materials");
+  if (d->n_materials == 0 && (d->n_prims || d->n_meshes)) return fail(RT_ERR_INVALID_ARGUMENT, "no materials");
   for (uint32_t i = 0; i < d->n_prims; i++) {
     uint8_t sh = d->prim_shape[i];
     if (sh > RT_SHAPE_BBOX) return fail(RT_ERR_INVALID_ARGUMENT, "unknown shape tag");
@@ -1121,13 +1209,98 @@ int validate(const rt_scene_desc* d) {
   if (d->n_lights && (!d->light_pos || !d->light_intensity)) return fail(RT_ERR_INVALID_ARGUMENT, "light tables missing");
   if (d->n_csgs && (!d->csg_op || !d->csg_left || !d->csg_right || !d->csg_depth))
     return fail(RT_ERR_INVALID_ARGUMENT, "csg tables missing");
+  if (d->n_meshes) {
+    if (!d->mesh || !d->mesh_bbox || !d->mesh_built || !d->mesh_material_begin || !d->mesh_material) return fail(RT_ERR_INVALID_ARGUMENT, "mesh tables missing");
+    int device = 0;
+    (void)hipGetDevice(&device);
+    if (d->mesh_material_begin[0] != 0) return fail(RT_ERR_INVALID_ARGUMENT, "mesh_material_begin must start at 0");
+    uint64_t total = 0;
+    for (uint32_t k = 0; k < d->n_meshes; k++) {
+      const rt_mesh* m = d->mesh[k];
+      if (!m) return fail(RT_ERR_INVALID_ARGUMENT, "a mesh is NULL");
+      if (!m->posed) return fail(RT_ERR_INVALID_ARGUMENT, "a mesh has not been posed (rt_mesh_pose) for this scene");
+      if (m->device != device) return fail(RT_ERR_INVALID_ARGUMENT, "a mesh lives on another device than the current one");
+      if (d->mesh_material_begin[k + 1] < d->mesh_material_begin[k] || d->mesh_material_begin[k + 1] - d->mesh_material_begin[k] != m->n_palette)
+        return fail(RT_ERR_INVALID_ARGUMENT, "mesh_material must hold one scene material per palette entry of each mesh");
+      for (uint32_t q = d->mesh_material_begin[k]; q < d->mesh_material_begin[k + 1]; q++)
+        if (d->mesh_material[q] >= d->n_materials) return fail(RT_ERR_INVALID_ARGUMENT, "mesh_material out of range");
+      total += m->n;
+    }
+    if (total + d->n_prims > RT_REF_INDEX_MASK) return fail(RT_ERR_UNSUPPORTED, "too many primitives");
+  }
   for (uint32_t i = 0; i < d->n_csgs; i++) {
+    if ((d->csg_left[i] >> RT_REF_KIND_SHIFT) == RT_REF_MESH || (d->csg_right[i] >> RT_REF_KIND_SHIFT) == RT_REF_MESH)
+      return fail(RT_ERR_UNSUPPORTED, "a device-resident mesh as a CSG operand is not supported");
     if (d->csg_op[i] > RT_CSG_DIFFERENCE) return fail(RT_ERR_INVALID_ARGUMENT, "unknown csg op");
     if (!ref_ok(d, d->csg_left[i]) || !ref_ok(d, d->csg_right[i])) return fail(RT_ERR_INVALID_ARGUMENT, "csg child out of range");
     if (d->csg_depth[i] >= RT_CSG_NEST_MAX)
       return fail(RT_ERR_UNSUPPORTED, "CSG objects nested deeper than RT_CSG_NEST_MAX (4) are not supported on the device");
   }
   return check_graph(d);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Device-side scene preparation (rt_mesh.h): the host side of rt_mesh_* and of the build rt_scene_create launches
+// ---------------------------------------------------------------------------------------------
+std::string mesh_status_text(uint32_t status) {
+  std::string t;
+  if (status & mesh::MESH_STATUS_NOT_FINITE) t += "a posed triangle's box has a coordinate that is not finite or beyond 1e18; ";
+  if (status & mesh::MESH_STATUS_UNORDERED) t += "the candidate planes of a group are not ordered (NaN coordinates); ";
+  if (status & mesh::MESH_STATUS_TOO_DEEP) t += "the tree is deeper than RT_MESH_MAX_LEVELS (64) levels; ";
+  return t + "prepare this frame on the host instead";
+}
+
+// ObjectGroup::build_bvh (group.rs:144-167) for the posed mesh, then its part of the scene's tables.  Synchronous: returns
+// when the tables are complete.  levels_out: levels of the tree (a mesh that keeps its flat child list: 1);
+// max_leaf_out: the most triangles a group that does not split holds.
+int mesh_build(rt_mesh* m, const mesh::MeshOut& out, bool built, uint32_t* levels_out, uint32_t* max_leaf_out) {
+  const mesh::MeshDev& M = m->dev;
+  hipStream_t st = m->stream;
+  const uint32_t grid = (m->n + RT_MESH_BLOCK - 1u) / RT_MESH_BLOCK;
+  HIP_TRY(hipMemsetAsync(M.dec, 0xFF, (size_t)m->n * sizeof(mesh::Dec), st));
+  HIP_TRY(hipMemsetAsync(M.bins, 0, (size_t)m->n * sizeof(mesh::Bin), st));
+  if (!m->acc_clean) {
+    const size_t items = (size_t)m->n * RT_MESH_ACC_PER_SEG;
+    hipLaunchKernelGGL(mesh::acc_reset_kernel, dim3((unsigned)((items + RT_MESH_BLOCK - 1u) / RT_MESH_BLOCK)), dim3(RT_MESH_BLOCK), 0, st, M);
+  }
+  m->acc_clean = false;
+  hipLaunchKernelGGL(mesh::begin_kernel, dim3(grid), dim3(RT_MESH_BLOCK), 0, st, M, out, built ? 1u : 0u);
+  uint32_t cur = 0, level = 0;
+  // levels to launch before looking: what the previous frame's tree needed and two more (the first frame: 2 log2 n)
+  uint32_t target = 0;
+  if (built) {
+    if (m->last_levels) target = m->last_levels + 2u;
+    else
+      for (uint32_t v = m->n; v; v >>= 1) target += 2u;
+    target = std::min<uint32_t>(std::max(target, 4u), RT_MESH_MAX_LEVELS);
+  }
+  for (;;) {
+    for (; level < target; level++) {
+      hipLaunchKernelGGL(mesh::bin_kernel, dim3(grid), dim3(RT_MESH_BLOCK), 0, st, M, cur, level);
+      hipLaunchKernelGGL(mesh::choose_kernel, dim3(grid), dim3(RT_MESH_BLOCK), 0, st, M, cur, level);
+      hipLaunchKernelGGL(mesh::count_kernel, dim3(grid), dim3(RT_MESH_BLOCK), 0, st, M, cur, level);
+      hipLaunchKernelGGL(mesh::scatter_kernel, dim3(grid), dim3(RT_MESH_BLOCK), 0, st, M, cur, level);
+      cur ^= 1u;
+    }
+    // (the tables are written optimistically: when the tree turns out to be unfinished they are simply written again)
+    hipLaunchKernelGGL(mesh::fold_kernel, dim3(grid), dim3(RT_MESH_BLOCK), 0, st, M, out);
+    hipLaunchKernelGGL(mesh::finalize_kernel, dim3(grid), dim3(RT_MESH_BLOCK), 0, st, M, out, cur);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(m->h_ctrl, M.ctrl, sizeof(mesh::Ctrl), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    if (m->h_ctrl->status) return fail(RT_ERR_UNSUPPORTED, "device-side scene preparation: " + mesh_status_text(m->h_ctrl->status));
+    if (built && level < RT_MESH_MAX_LEVELS && m->h_ctrl->active[level] != 0u) {
+      target = std::min<uint32_t>(level + 8u, RT_MESH_MAX_LEVELS);
+      continue;
+    }
+    break;
+  }
+  m->acc_clean = true;
+  m->cur = cur;
+  m->last_levels = m->h_ctrl->max_level + 2u;  // (levels 0..max_level split or stopped; their children are one level further)
+  *levels_out = m->last_levels;
+  *max_leaf_out = m->h_ctrl->max_leaf;
+  return RT_OK;
 }
 
 DevOptions dev_options(const rt_options* o) {
@@ -1917,10 +2090,17 @@ int rt_scene_create(const rt_scene_desc* d, rt_scene** out) try {
   };
   entries[0].ref = RT_MAKE_REF(RT_REF_NODE, 0);  // (the vector's elements are value-initialised: all zero)
   fill_node_fields(entries[0], 0);
+  std::vector<uint32_t> mesh_root_entry(d->n_meshes, 0u);
   for (uint32_t i = 0; i < d->n_child_refs; i++) {
     DevEntry& e = entries[(size_t)i + 1];
     e.ref = d->child_ref[i];
     if ((e.ref >> RT_REF_KIND_SHIFT) == RT_REF_NODE) fill_node_fields(e, e.ref & RT_REF_INDEX_MASK);
+    if ((e.ref >> RT_REF_KIND_SHIFT) == RT_REF_MESH) {  // a group for the walk; its child range is written by the device build
+      const uint32_t k = e.ref & RT_REF_INDEX_MASK;
+      std::memcpy(e.bb, d->mesh_bbox + (size_t)k * 6, sizeof(double) * 6);
+      e.ref = RT_MAKE_REF(RT_REF_NODE, 0);
+      mesh_root_entry[k] = i + 1;
+    }
   }
   // a group that is a CSG operand (csg.rs:113-115) is walked from a record of its own, appended here; the device's CSG
   // tables refer to it by RT_MAKE_REF(RT_REF_NODE, record index)
@@ -1948,6 +2128,33 @@ int rt_scene_create(const rt_scene_desc* d, rt_scene** out) try {
   if (L.stack_need > RT_FAST_STACK_MAX)
     return fail(RT_ERR_UNSUPPORTED, "the BVH needs a device traversal stack of " + std::to_string(L.stack_need) + " entries; it holds " +
                                         std::to_string(RT_FAST_STACK_MAX));
+  // The meshes' ranges in the tables (filled by the device, rt_mesh.h): behind the scene's own parts.
+  struct MeshRange {
+    uint32_t node0, tri0, prim0, entry_groups0, entry_prims0, mat0;
+  };
+  std::vector<MeshRange> mesh_range(d->n_meshes);
+  uint64_t mesh_tris_total = 0, mesh_nodes_total = 0, mesh_entries_total = 0;
+  {
+    for (uint32_t k = 0; k < d->n_meshes; k++) {
+      const uint32_t n = d->mesh[k]->n;
+      MeshRange& r = mesh_range[k];
+      r.node0 = (uint32_t)(std::max<size_t>(L.nodes.size(), (size_t)RT_LDS_NODES) + mesh_nodes_total);
+      r.tri0 = (uint32_t)(L.n_dev_tris + mesh_tris_total);
+      r.prim0 = (uint32_t)(d->n_prims + mesh_tris_total);
+      r.entry_groups0 = (uint32_t)(entries.size() + mesh_entries_total);
+      r.entry_prims0 = r.entry_groups0 + 2u * n;
+      r.mat0 = d->mesh_material_begin[k];
+      mesh_tris_total += n;
+      mesh_nodes_total += 2ull * n;
+      mesh_entries_total += 3ull * n;
+    }
+    if (L.nodes.size() + mesh_nodes_total > RT_FREF_INDEX_MASK || L.n_dev_tris + mesh_tris_total > RT_FREF_INDEX_MASK)
+      return fail(RT_ERR_UNSUPPORTED, "scene too large for 24-bit node/triangle indices");
+    if (entries.size() + mesh_entries_total > 0xFFFFFFFFull) return fail(RT_ERR_UNSUPPORTED, "scene too large for 32-bit child records");
+    for (DevNode& n : L.nodes)
+      for (int c = 0; c < RT_NODE_WIDTH; c++)
+        if (RT_IS_MESH_MARKER(n.ref[c])) n.ref[c] = RT_MAKE_FREF(RT_FREF_INNER, 0, mesh_range[n.ref[c] & RT_FREF_INDEX_MASK].node0);
+  }
   std::vector<uint4> prim_info(d->n_prims);
   for (uint32_t i = 0; i < d->n_prims; i++) {
     bool tri = d->prim_shape[i] == RT_SHAPE_TRIANGLE || d->prim_shape[i] == RT_SHAPE_SMOOTH_TRIANGLE;
@@ -1999,7 +2206,12 @@ int rt_scene_create(const rt_scene_desc* d, rt_scene** out) try {
     UP(_v, field);                                     \
   } while (0)
   if (L.nodes.size() < (size_t)RT_LDS_NODES) L.nodes.resize(RT_LDS_NODES);  // (the trace kernels copy that many to LDS)
-  UP(L.nodes, nodes);
+#define UPT(vec, field, tail)                          \
+  do {                                                 \
+    rc = upload(sc, vec, &sc->dev.field, (size_t)(tail)); \
+    if (rc) return rc;                                 \
+  } while (0)
+  UPT(L.nodes, nodes, mesh_nodes_total);
   UP(L.leaf_ref, leaf_ref);
   {
     std::vector<DevLeafRec> recs(L.leaf_ref.size());
@@ -2050,10 +2262,13 @@ int rt_scene_create(const rt_scene_desc* d, rt_scene** out) try {
     UP(csg2, csg2_rec);
     UP(recs, leaf_rec);
   }
-  UP(L.prim_rank, prim_rank);
-  UP(entries, entries);
-  UP(prim_info, prim_info);
-  UPA(uint32_t, d->prim_csg_left, d->n_prims, prim_csg_left);
+  UPT(L.prim_rank, prim_rank, mesh_tris_total);
+  UPT(entries, entries, mesh_entries_total);
+  UPT(prim_info, prim_info, mesh_tris_total);
+  {
+    std::vector<uint32_t> v(d->prim_csg_left, d->prim_csg_left + d->n_prims);
+    UPT(v, prim_csg_left, mesh_tris_total);
+  }
   {
     // bit 0: a closest hit on this primitive is followed by the container walk (get_refractive, intersection.rs:258-302).
     // The walk only ever COPIES refractive indices out of the material table (or the constant 1.0 of air): when every
@@ -2068,11 +2283,31 @@ int rt_scene_create(const rt_scene_desc* d, rt_scene** out) try {
       if (!(tr == 0. || std::fabs(tr - 0.) < 1.0e-8)) flags[i] = 1;  // !approx_eq(transparency, 0) (approx_eq.rs:16-20)
     }
     sc->has_walks = std::find(flags.begin(), flags.end(), (uint8_t)1) != flags.end();
-    UP(flags, prim_flags);
+    UPT(flags, prim_flags, mesh_tris_total);
+    // the meshes' palettes in terms of this scene's materials: index, "opaque" (rt_device.h RT_TRI_OPAQUE_BIT), "walk follows"
+    std::vector<uint32_t> mat_map(d->mesh_material, d->mesh_material + (d->n_meshes ? d->mesh_material_begin[d->n_meshes] : 0u));
+    std::vector<uint8_t> mat_flags(mat_map.size(), 0);
+    for (size_t q = 0; q < mat_map.size(); q++) {
+      const double tr = d->material[(size_t)mat_map[q] * RT_MAT_STRIDE + RT_MAT_TRANSPARENCY];
+      if (tr == 0.) mat_flags[q] |= 1u;
+      if (walk_matters && !(tr == 0. || std::fabs(tr - 0.) < 1.0e-8)) {
+        mat_flags[q] |= 2u;
+        sc->has_walks = true;
+      }
+    }
+    stage_bytes(sc, mat_map.data(), mat_map.size() * sizeof(uint32_t), (void*)&sc->mesh_mat_map);
+    stage_bytes(sc, mat_flags.data(), mat_flags.size(), (void*)&sc->mesh_mat_flags);
   }
   UPA(double, d->xform_inv, (size_t)d->n_xforms * 16, xform_inv);
-  UP(tri_isect, tri_isect);
-  UP(tri_norm, tri_norm);
+  UPT(tri_isect, tri_isect, mesh_tris_total * RT_TRI_STRIDE);
+  UPT(tri_norm, tri_norm, mesh_tris_total * 9);
+  sc->table_bytes[0] = (tri_isect.size() + mesh_tris_total * RT_TRI_STRIDE) * sizeof(double);
+  sc->table_bytes[1] = (tri_norm.size() + mesh_tris_total * 9) * sizeof(double);
+  sc->table_bytes[2] = (d->n_prims + mesh_tris_total) * sizeof(uint32_t);
+  sc->table_bytes[3] = (d->n_prims + mesh_tris_total) * sizeof(uint4);
+  sc->table_bytes[4] = (entries.size() + mesh_entries_total) * sizeof(DevEntry);
+  sc->table_bytes[5] = (L.nodes.size() + mesh_nodes_total) * sizeof(DevNode);
+  sc->table_bytes[6] = d->n_prims + mesh_tris_total;
   UP(quadric, quadric);
   UPA(uint8_t, d->quadric_closed, d->n_quadrics, quadric_closed);
   UPA(uint8_t, d->csg_op, d->n_csgs, csg_op);
@@ -2088,11 +2323,12 @@ int rt_scene_create(const rt_scene_desc* d, rt_scene** out) try {
   UPA(double, d->light_intensity, (size_t)d->n_lights * 3, light_intensity);
 #undef UP
 #undef UPA
+#undef UPT
   sc->dev.n_lights = d->n_lights;
-  sc->dev.n_prims = d->n_prims;
+  sc->dev.n_prims = (uint32_t)(d->n_prims + mesh_tris_total);
   sc->n_lights = d->n_lights;
   sc->has_csg = d->n_csgs > 0;
-  sc->shape = ((uint64_t)d->n_prims << 40) ^ ((uint64_t)d->n_nodes << 20) ^ ((uint64_t)d->n_lights << 8) ^ (uint64_t)d->n_materials;
+  sc->shape = ((uint64_t)(d->n_prims + mesh_tris_total) << 40) ^ ((uint64_t)d->n_nodes << 20) ^ ((uint64_t)d->n_lights << 8) ^ (uint64_t)d->n_materials;
   (void)g_learned.lookup(sc->device, sc->shape, &sc->nodes_per_sample, &sc->ratio_floor);
   if (const char* e = std::getenv("RT_STREAM_NODES_PER_SAMPLE")) {  // where the adaptive ratio starts (tests start it too low)
     unsigned long v = std::strtoul(e, nullptr, 10);
@@ -2116,8 +2352,195 @@ int rt_scene_create(const rt_scene_desc* d, rt_scene** out) try {
   for (uint32_t l = 0; rc == RT_OK && l <= RT_MAX_DEPTH; l++)
     if (hipEventCreateWithFlags(&sc->level_event[l], hipEventDisableTiming) != hipSuccess) rc = fail(RT_ERR_DEVICE, "hipEventCreate failed");
   if (rc) return rc;
+  // The meshes' subtrees and their parts of the tables, on the device (the scene's own parts are in place: commit_arena has
+  // waited for the upload).
+  if (d->n_meshes) {
+    MeshNeeds needs;
+    needs.sub.assign(d->n_meshes, 0u);
+    uint32_t fast_need = L.stack_need;
+    for (uint32_t k = 0; k < d->n_meshes; k++) {
+      rt_mesh* m = d->mesh[k];
+      mesh::MeshOut o;
+      o.nodes = const_cast<DevNode*>(sc->dev.nodes);
+      o.tri_isect = const_cast<double*>(sc->dev.tri_isect);
+      o.tri_norm = const_cast<double*>(sc->dev.tri_norm);
+      o.prim_rank = const_cast<uint32_t*>(sc->dev.prim_rank);
+      o.prim_info = const_cast<uint4*>(sc->dev.prim_info);
+      o.prim_csg_left = const_cast<uint32_t*>(sc->dev.prim_csg_left);
+      o.prim_flags = const_cast<uint8_t*>(sc->dev.prim_flags);
+      o.entries = const_cast<DevEntry*>(sc->dev.entries);
+      o.mat_map = sc->mesh_mat_map + mesh_range[k].mat0;
+      o.mat_flags = sc->mesh_mat_flags + mesh_range[k].mat0;
+      o.node0 = mesh_range[k].node0;
+      o.tri0 = mesh_range[k].tri0;
+      o.prim0 = mesh_range[k].prim0;
+      o.rank0 = L.mesh_rank0[k];
+      o.entry_groups0 = mesh_range[k].entry_groups0;
+      o.entry_prims0 = mesh_range[k].entry_prims0;
+      o.root_entry = mesh_root_entry[k];
+      o.built = d->mesh_built[k] ? 1u : 0u;
+      std::memcpy(o.group_bb, d->mesh_bbox + (size_t)k * 6, sizeof(o.group_bb));
+      uint32_t levels = 0, max_leaf = 0;
+      rc = mesh_build(m, o, d->mesh_built[k] != 0, &levels, &max_leaf);
+      if (rc) return rc;
+      m->posed = false;  // (the scene has its own copy of everything: the mesh is free for the next frame's pose)
+      // Stack entries the mesh's tree can add.  Reference-order walk: a binary tree of `levels` levels holds at most one
+      // sibling per level.  Fast path: a 4-wide node per two levels, at most 3 entries held per node; a leaf group of more
+      // than one run is a chain of nodes, 3 runs each.
+      needs.sub[k] = levels + 1u;
+      uint32_t fast = 3u * ((levels + 1u) / 2u + 1u);
+      if (max_leaf > RT_FREF_LEAF_MAX) fast += 3u * ((max_leaf + 3u * RT_FREF_LEAF_MAX - 1u) / (3u * RT_FREF_LEAF_MAX));
+      fast_need = std::max(fast_need, L.mesh_held[k] + fast);
+    }
+    std::fill(memo.begin(), memo.end(), (int64_t)-1);
+    const uint32_t need_all = stack_need(d, 0, memo, 0, &needs);
+    if (need_all > RT_STACK_MAX)
+      return fail(RT_ERR_UNSUPPORTED, "the BVH (with the device-built subtrees) needs a traversal stack of " + std::to_string(need_all) +
+                                          " entries; the device limit is " + std::to_string(RT_STACK_MAX));
+    if (fast_need > RT_FAST_STACK_MAX)
+      return fail(RT_ERR_UNSUPPORTED, "the BVH (with the device-built subtrees) needs a device traversal stack of " + std::to_string(fast_need) +
+                                          " entries; it holds " + std::to_string(RT_FAST_STACK_MAX));
+  }
   *out = owner.release();
   return RT_OK;
+} RT_NO_UNWIND
+
+int rt_mesh_create(const rt_mesh_desc* d, rt_mesh** out) try {
+  if (!out) return fail(RT_ERR_INVALID_ARGUMENT, "out is NULL");
+  *out = nullptr;
+  if (!d || d->n_tris == 0 || !d->shape || !d->p1 || !d->p2 || !d->p3 || !d->bbox || !d->material || d->n_palette == 0)
+    return fail(RT_ERR_INVALID_ARGUMENT, "rt_mesh_desc: triangles, boxes and materials are required");
+  if (d->n_tris > RT_MESH_MAX_TRIS) return fail(RT_ERR_UNSUPPORTED, "a mesh holds at most " + std::to_string(RT_MESH_MAX_TRIS) + " triangles");
+  const uint32_t n = d->n_tris;
+  bool any_smooth = false;
+  for (uint32_t i = 0; i < n; i++) {
+    if (d->shape[i] != RT_SHAPE_TRIANGLE && d->shape[i] != RT_SHAPE_SMOOTH_TRIANGLE) return fail(RT_ERR_INVALID_ARGUMENT, "a mesh holds triangles only");
+    if (d->material[i] >= d->n_palette) return fail(RT_ERR_INVALID_ARGUMENT, "rt_mesh_desc.material out of range");
+    any_smooth = any_smooth || d->shape[i] == RT_SHAPE_SMOOTH_TRIANGLE;
+  }
+  if (any_smooth && (!d->n1 || !d->n2 || !d->n3)) return fail(RT_ERR_INVALID_ARGUMENT, "smooth triangles need n1, n2, n3");
+  std::unique_ptr<rt_mesh> owner(new rt_mesh());
+  rt_mesh* m = owner.get();
+  m->n = n;
+  m->n_palette = d->n_palette;
+  (void)hipGetDevice(&m->device);
+  // one block: [base pose | frame pose | build state]; the base pose is staged on the host and copied in one go
+  size_t off = 0;
+  auto take = [&](size_t bytes) {
+    size_t at = off;
+    off = (off + bytes + 255) & ~(size_t)255;
+    return at;
+  };
+  const size_t v3 = (size_t)n * 3 * sizeof(double);
+  const size_t o_p1 = take(v3), o_p2 = take(v3), o_p3 = take(v3), o_n1 = take(v3), o_n2 = take(v3), o_n3 = take(v3);
+  const size_t o_bbox = take(2 * v3), o_mat = take((size_t)n * 4), o_shape = take(n);
+  const size_t base_bytes = off;
+  const size_t o_q1 = take(v3), o_e1 = take(v3), o_e2 = take(v3), o_m1 = take(v3), o_m2 = take(v3), o_m3 = take(v3);
+  const size_t o_pbb = take(2 * v3), o_ctr = take(v3), o_box = take(6 * sizeof(unsigned long long));
+  const size_t o_ord0 = take((size_t)n * 4), o_ord1 = take((size_t)n * 4), o_seg0 = take((size_t)n * 4), o_seg1 = take((size_t)n * 4);
+  const size_t o_segs = take((size_t)n * sizeof(mesh::Seg)), o_dec = take((size_t)n * sizeof(mesh::Dec));
+  const size_t o_acc = take((size_t)n * RT_MESH_ACC_PER_SEG * sizeof(mesh::Acc)), o_bins = take((size_t)n * sizeof(mesh::Bin));
+  const size_t o_bsum = take((size_t)RT_MESH_MAX_BLOCKS * 4), o_tail = take((size_t)n * 4), o_ctrl = take(sizeof(mesh::Ctrl));
+  m->block_bytes = off;
+  if (hipMalloc(&m->block, m->block_bytes) != hipSuccess) {
+    (void)hipGetLastError();
+    m->block = nullptr;
+    return fail(RT_ERR_DEVICE, "hipMalloc of a mesh (" + std::to_string(m->block_bytes >> 20) + " MiB) failed");
+  }
+  {
+    std::vector<char> stage(base_bytes, 0);
+    std::memcpy(stage.data() + o_p1, d->p1, v3);
+    std::memcpy(stage.data() + o_p2, d->p2, v3);
+    std::memcpy(stage.data() + o_p3, d->p3, v3);
+    if (d->n1) std::memcpy(stage.data() + o_n1, d->n1, v3);
+    if (d->n2) std::memcpy(stage.data() + o_n2, d->n2, v3);
+    if (d->n3) std::memcpy(stage.data() + o_n3, d->n3, v3);
+    std::memcpy(stage.data() + o_bbox, d->bbox, 2 * v3);
+    std::memcpy(stage.data() + o_mat, d->material, (size_t)n * 4);
+    std::memcpy(stage.data() + o_shape, d->shape, n);
+    HIP_TRY(hipMemcpy(m->block, stage.data(), base_bytes, hipMemcpyHostToDevice));
+  }
+  char* b = (char*)m->block;
+  mesh::MeshDev& M = m->dev;
+  M.n = n;
+  M.shape = (const uint8_t*)(b + o_shape);
+  M.p1 = (const double*)(b + o_p1);
+  M.p2 = (const double*)(b + o_p2);
+  M.p3 = (const double*)(b + o_p3);
+  M.n1 = (const double*)(b + o_n1);
+  M.n2 = (const double*)(b + o_n2);
+  M.n3 = (const double*)(b + o_n3);
+  M.bbox = (const double*)(b + o_bbox);
+  M.mat = (const uint32_t*)(b + o_mat);
+  M.q1 = (double*)(b + o_q1);
+  M.e1 = (double*)(b + o_e1);
+  M.e2 = (double*)(b + o_e2);
+  M.m1 = (double*)(b + o_m1);
+  M.m2 = (double*)(b + o_m2);
+  M.m3 = (double*)(b + o_m3);
+  M.pbb = (double*)(b + o_pbb);
+  M.ctr = (double*)(b + o_ctr);
+  M.pose_box = (unsigned long long*)(b + o_box);
+  M.order[0] = (uint32_t*)(b + o_ord0);
+  M.order[1] = (uint32_t*)(b + o_ord1);
+  M.seg_of[0] = (uint32_t*)(b + o_seg0);
+  M.seg_of[1] = (uint32_t*)(b + o_seg1);
+  M.segs = (mesh::Seg*)(b + o_segs);
+  M.dec = (mesh::Dec*)(b + o_dec);
+  M.acc = (mesh::Acc*)(b + o_acc);
+  M.bins = (mesh::Bin*)(b + o_bins);
+  M.blocksum = (uint32_t*)(b + o_bsum);
+  M.segtail = (uint32_t*)(b + o_tail);
+  M.ctrl = (mesh::Ctrl*)(b + o_ctrl);
+  HIP_TRY(hipMemset(M.ctrl, 0, sizeof(mesh::Ctrl)));
+  HIP_TRY(hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking));
+  void* pinned = nullptr;
+  HIP_TRY(hipHostMalloc(&pinned, 64 + sizeof(mesh::Ctrl), hipHostMallocPortable));
+  m->h_box = (unsigned long long*)pinned;
+  m->h_ctrl = (mesh::Ctrl*)((char*)pinned + 64);
+  *out = owner.release();
+  return RT_OK;
+} RT_NO_UNWIND
+
+void rt_mesh_destroy(rt_mesh* mesh) { delete mesh; }
+
+int rt_mesh_pose(rt_mesh* m, uint32_t n_matrices, const double* matrices, double* out_bbox6) try {
+  if (!m || (n_matrices && !matrices)) return fail(RT_ERR_INVALID_ARGUMENT, "bad arguments to rt_mesh_pose");
+  if (n_matrices > RT_MESH_MAX_MATRICES)
+    return fail(RT_ERR_UNSUPPORTED, "rt_mesh_pose applies at most RT_MESH_MAX_MATRICES (8) matrices per frame");
+  int device = 0;
+  (void)hipGetDevice(&device);
+  if (device != m->device) return fail(RT_ERR_INVALID_ARGUMENT, "the mesh lives on another device than the current one");
+  mesh::PoseArgs a;
+  std::memset(&a, 0, sizeof(a));
+  a.n_mats = n_matrices;
+  if (n_matrices) std::memcpy(a.m, matrices, (size_t)n_matrices * 16 * sizeof(double));
+  const uint32_t grid = (m->n + RT_MESH_BLOCK - 1u) / RT_MESH_BLOCK;
+  m->posed = false;
+  HIP_TRY(hipMemsetAsync(&m->dev.ctrl->status, 0, sizeof(uint32_t), m->stream));
+  hipLaunchKernelGGL(mesh::pose_init_kernel, dim3(1), dim3(RT_MESH_BLOCK), 0, m->stream, m->dev);
+  hipLaunchKernelGGL(mesh::pose_kernel, dim3(grid), dim3(RT_MESH_BLOCK), 0, m->stream, m->dev, a);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(m->h_box, m->dev.pose_box, 6 * sizeof(unsigned long long), hipMemcpyDeviceToHost, m->stream));
+  HIP_TRY(hipMemcpyAsync(m->h_ctrl, m->dev.ctrl, sizeof(mesh::Ctrl), hipMemcpyDeviceToHost, m->stream));
+  HIP_TRY(hipStreamSynchronize(m->stream));
+  if (m->h_ctrl->status) return fail(RT_ERR_UNSUPPORTED, "rt_mesh_pose: " + mesh_status_text(m->h_ctrl->status));
+  for (int k = 0; k < 6; k++) {  // (mesh::dunkey on the host)
+    const unsigned long long key = m->h_box[k], u = (key >> 63) ? (key & 0x7FFFFFFFFFFFFFFFull) : ~key;
+    std::memcpy(&m->bbox[k], &u, sizeof(double));
+  }
+  if (out_bbox6) std::memcpy(out_bbox6, m->bbox, sizeof(m->bbox));
+  m->posed = true;
+  return RT_OK;
+} RT_NO_UNWIND
+
+long long rt_scene_debug_table(const rt_scene* scene, int which, void* out, unsigned long long capacity) try {
+  if (!scene || which < 0 || which > 6 || (!out && capacity)) return fail(RT_ERR_INVALID_ARGUMENT, "bad arguments to rt_scene_debug_table");
+  const void* src[7] = {scene->dev.tri_isect, scene->dev.tri_norm, scene->dev.prim_rank, scene->dev.prim_info,
+                        scene->dev.entries,   scene->dev.nodes,    scene->dev.prim_flags};
+  const size_t bytes = scene->table_bytes[which], n = (size_t)std::min<unsigned long long>(bytes, capacity);
+  if (n) HIP_TRY(hipMemcpy(out, src[which], n, hipMemcpyDeviceToHost));
+  return (long long)bytes;
 } RT_NO_UNWIND
 
 void rt_scene_destroy(rt_scene* scene) { delete scene; }

@@ -34,6 +34,10 @@ struct FlatScene {
   std::vector<double> material, pattern_c1, pattern_c2, pattern_inv;
   std::vector<uint8_t> pattern_kind;
   std::vector<double> light_pos, light_intensity;
+  std::vector<rt_mesh*> mesh;
+  std::vector<uint8_t> mesh_built;
+  std::vector<double> mesh_bbox;
+  std::vector<uint32_t> mesh_material_begin, mesh_material;
   // scratch while flattening
   std::vector<std::vector<uint32_t>> node_children;
   std::map<std::string, uint32_t> material_index;
@@ -44,7 +48,8 @@ struct FlatScene {
     tri_e2.clear(); tri_n1.clear(); tri_n2.clear(); tri_n3.clear(); quadric_y_min.clear(); quadric_y_max.clear();
     quadric_closed.clear(); csg_op.clear(); csg_depth.clear(); csg_left.clear(); csg_right.clear(); material.clear();
     pattern_c1.clear(); pattern_c2.clear(); pattern_inv.clear(); pattern_kind.clear(); light_pos.clear();
-    light_intensity.clear(); node_children.clear(); material_index.clear();
+    light_intensity.clear(); node_children.clear(); material_index.clear(); mesh.clear(); mesh_built.clear(); mesh_bbox.clear();
+    mesh_material_begin.clear(); mesh_material.clear();
   }
 };
 
@@ -54,7 +59,18 @@ struct Frame {  // one rts_flatten_frame result
   ObjectPtr root;
   Builder* owner = nullptr;
 };
+// librtcore's mesh entry points (include/rtcore.h), handed over by rts_extract_meshes: this library does not link HIP.
+typedef int (*rt_mesh_create_fn)(const rt_mesh_desc*, rt_mesh**);
+typedef void (*rt_mesh_destroy_fn)(rt_mesh*);
+typedef int (*rt_mesh_pose_fn)(rt_mesh*, uint32_t, const double*, double*);
+struct MeshRec {
+  rt_mesh* handle = nullptr;
+  std::vector<Material> palette;
+};
 struct Builder {
+  std::vector<MeshRec> meshes;   // device-resident triangle groups behind the proxies of the tree (Object::mesh_id)
+  rt_mesh_destroy_fn mesh_destroy = nullptr;
+  rt_mesh_pose_fn mesh_pose = nullptr;
   std::vector<ObjectPtr> arena;  // handles
   ObjectPtr root = make_group({});
   std::vector<Light> lights;
@@ -66,6 +82,9 @@ struct Builder {
   std::vector<Frame*> pool;
   ~Builder() {
     for (Frame* f : pool) delete f;
+    if (mesh_destroy)
+      for (MeshRec& m : meshes)
+        if (m.handle) mesh_destroy(m.handle);
   }
 };
 
@@ -95,17 +114,26 @@ uint32_t material_id(FlatScene& f, const Material& m) {
   return id;
 }
 
-bool flatten_object(FlatScene& f, const Object& o, std::vector<const Object*>& csg_chain, uint32_t& out_ref);
+// reached: ObjectGroup::build_bvh was called on this object's parent and went on into its children (group.rs:145-152,
+// 157-166): every ancestor has at most two children after the build.  What a mesh proxy needs to know: whether the device
+// builds its subtree or it keeps its flat child list (group.rs:153-156 returns without visiting nested groups).
+struct FlattenCtx {
+  const Builder* builder = nullptr;
+  bool build_bvh = false;
+};
+thread_local FlattenCtx t_ctx;
+bool flatten_object(FlatScene& f, const Object& o, std::vector<const Object*>& csg_chain, uint32_t& out_ref, bool reached);
 
-bool flatten_group(FlatScene& f, const Object& g, std::vector<const Object*>& csg_chain, uint32_t& out_index) {
+bool flatten_group(FlatScene& f, const Object& g, std::vector<const Object*>& csg_chain, uint32_t& out_index, bool reached) {
   uint32_t idx = (uint32_t)f.node_children.size();
   f.node_children.emplace_back();
   const double bb[6] = {g.bbox.min.x, g.bbox.min.y, g.bbox.min.z, g.bbox.max.x, g.bbox.max.y, g.bbox.max.z};
   f.node_bbox.insert(f.node_bbox.end(), bb, bb + 6);
   std::vector<uint32_t> refs;
+  const bool children_reached = reached && g.children.size() <= 2;
   for (const auto& c : g.children) {
     uint32_t r;
-    if (!flatten_object(f, *c, csg_chain, r)) return false;
+    if (!flatten_object(f, *c, csg_chain, r, children_reached)) return false;
     refs.push_back(r);
   }
   f.node_children[idx] = std::move(refs);
@@ -113,10 +141,36 @@ bool flatten_group(FlatScene& f, const Object& g, std::vector<const Object*>& cs
   return true;
 }
 
-bool flatten_object(FlatScene& f, const Object& o, std::vector<const Object*>& csg_chain, uint32_t& out_ref) {
+uint32_t material_id(FlatScene& f, const Material& m);
+bool flatten_object(FlatScene& f, const Object& o, std::vector<const Object*>& csg_chain, uint32_t& out_ref, bool reached) {
+  if (o.kind == OBJ_GROUP && o.mesh_id >= 0) {  // a device-resident mesh: RT_REF_MESH, its triangles stay where they are
+    if (!csg_chain.empty()) {
+      g_err = "a mesh proxy inside a CSG object";
+      return false;
+    }
+    const MeshRec& rec = t_ctx.builder->meshes[(size_t)o.mesh_id];
+    // (the group's box as the tree holds it: on the `image` path nothing recalculated it, group.rs:263-270)
+    const double gb[6] = {o.bbox.min.x, o.bbox.min.y, o.bbox.min.z, o.bbox.max.x, o.bbox.max.y, o.bbox.max.z};
+    if (!o.mesh_posed) {  // the `image` path: the device has yet to take the base pose (with what the proxy collected)
+      Object tmp;
+      tmp.kind = OBJ_GROUP;
+      tmp.mesh_id = o.mesh_id;
+      tmp.mesh_pending = o.mesh_pending;
+      if (!mesh_pose_hook(tmp, mesh_pose_user)) return false;
+    }
+    const uint32_t k = (uint32_t)f.mesh.size();
+    f.mesh.push_back(rec.handle);
+    f.mesh_bbox.insert(f.mesh_bbox.end(), gb, gb + 6);
+    f.mesh_built.push_back(reached ? 1 : 0);
+    if (f.mesh_material_begin.empty()) f.mesh_material_begin.push_back(0);
+    for (const Material& m : rec.palette) f.mesh_material.push_back(material_id(f, m));
+    f.mesh_material_begin.push_back((uint32_t)f.mesh_material.size());
+    out_ref = RT_MAKE_REF(RT_REF_MESH, k);
+    return true;
+  }
   if (o.kind == OBJ_GROUP) {
     uint32_t idx;
-    if (!flatten_group(f, o, csg_chain, idx)) return false;
+    if (!flatten_group(f, o, csg_chain, idx, reached)) return false;
     out_ref = RT_MAKE_REF(RT_REF_NODE, idx);
     return true;
   }
@@ -132,8 +186,8 @@ bool flatten_object(FlatScene& f, const Object& o, std::vector<const Object*>& c
     f.csg_right.push_back(0);
     csg_chain.push_back(&o);
     uint32_t l, r;
-    if (!flatten_object(f, *o.left, csg_chain, l)) return false;
-    if (!flatten_object(f, *o.right, csg_chain, r)) return false;
+    if (!flatten_object(f, *o.left, csg_chain, l, false)) return false;
+    if (!flatten_object(f, *o.right, csg_chain, r, false)) return false;
     csg_chain.pop_back();
     f.csg_left[idx] = l;
     f.csg_right[idx] = r;
@@ -527,15 +581,40 @@ void rts_frame_free(void* frame) {
   delete fr;
 }
 
+// Object::recalculate_bbox of a mesh proxy: the matrices it collected go to the device (rt_mesh_pose), the union of the
+// children's boxes comes back.
+static bool pose_proxy(Object& proxy, void* user) {
+  const Builder* b = (const Builder*)user;
+  if (!b || !b->mesh_pose || proxy.mesh_id < 0 || (size_t)proxy.mesh_id >= b->meshes.size()) {
+    g_err = "mesh proxy without a device mesh behind it";
+    return false;
+  }
+  std::vector<double> mats;
+  for (const Mat4& m : proxy.mesh_pending) mats.insert(mats.end(), m.d, m.d + 16);
+  double bb[6];
+  if (b->mesh_pose(b->meshes[(size_t)proxy.mesh_id].handle, (uint32_t)proxy.mesh_pending.size(), mats.empty() ? nullptr : mats.data(), bb) != 0) {
+    g_err = "rt_mesh_pose failed (see rt_last_error)";
+    return false;
+  }
+  proxy.bbox.min = {bb[0], bb[1], bb[2]};
+  proxy.bbox.max = {bb[3], bb[4], bb[5]};
+  proxy.mesh_posed = true;
+  return true;
+}
+
 static int flatten_frame(const Builder* b, double animate_time, int build_bvh, FlatScene& f, ObjectPtr& frame_root,
                          rt_scene_desc* out) {
+  mesh_pose_hook = pose_proxy;
+  mesh_pose_user = (void*)b;
+  t_ctx.builder = b;
+  t_ctx.build_bvh = build_bvh != 0;
   frame_root = b->root->clone();
   if (animate_time == animate_time) frame_root->group_animate(animate_time);
   if (build_bvh == 2) frame_root->build_bvh_plain();
   else if (build_bvh) frame_root->build_bvh();
   std::vector<const Object*> chain;
   uint32_t root_idx;
-  if (!flatten_group(f, *frame_root, chain, root_idx)) return -1;
+  if (!flatten_group(f, *frame_root, chain, root_idx, build_bvh != 0)) return -1;
   f.node_child_begin.push_back(0);
   for (auto& v : f.node_children) {
     f.child_ref.insert(f.child_ref.end(), v.begin(), v.end());
@@ -585,7 +664,99 @@ static int flatten_frame(const Builder* b, double animate_time, int build_bvh, F
   out->n_lights = (uint32_t)(f.light_pos.size() / 3);
   out->light_pos = ptr_or_null(f.light_pos);
   out->light_intensity = ptr_or_null(f.light_intensity);
+  out->n_meshes = (uint32_t)f.mesh.size();
+  out->mesh = ptr_or_null(f.mesh);
+  out->mesh_bbox = ptr_or_null(f.mesh_bbox);
+  out->mesh_built = ptr_or_null(f.mesh_built);
+  out->mesh_material_begin = ptr_or_null(f.mesh_material_begin);
+  out->mesh_material = ptr_or_null(f.mesh_material);
   return 0;
 }
+
+// Moves every group of at least min_tris children that are ALL plain triangle primitives (what obj_model.rs makes of an OBJ
+// file or of one of its `g` groups) onto the device: the group stays in the tree as a proxy (Object::mesh_id) with its box and
+// primitive count, its children become an rt_mesh.  Groups inside CSG objects are left alone.  create / pose / destroy are
+// librtcore's rt_mesh_create / rt_mesh_pose / rt_mesh_destroy.  Returns the number of meshes made, < 0 on error.
+// Call it once, when the scene is complete (set_material and transforms on the objects are over).
+static int extract_in(Builder* b, Object& g, size_t min_tris, rt_mesh_create_fn create) {
+  int made = 0;
+  for (auto& cp : g.children) {
+    Object& c = *cp;
+    if (c.kind != OBJ_GROUP || c.mesh_id >= 0) continue;
+    bool all_tris = c.children.size() >= min_tris && !c.children.empty();
+    for (const auto& t : c.children) {
+      if (!all_tris) break;
+      all_tris = t->kind == OBJ_PRIMITIVE && (t->shape == RT_SHAPE_TRIANGLE || t->shape == RT_SHAPE_SMOOTH_TRIANGLE) && !t->has_inv &&
+                 t->animations.empty();
+    }
+    if (!all_tris) {
+      int r = extract_in(b, c, min_tris, create);
+      if (r < 0) return r;
+      made += r;
+      continue;
+    }
+    const size_t n = c.children.size();
+    MeshRec rec;
+    std::vector<uint8_t> shape(n);
+    std::vector<double> p1, p2, p3, n1, n2, n3, bbox;
+    std::vector<uint32_t> mat(n);
+    std::map<std::string, uint32_t> palette_index;
+    for (size_t i = 0; i < n; i++) {
+      const Object& t = *c.children[i];
+      shape[i] = (uint8_t)t.shape;
+      push3(p1, t.p1); push3(p2, t.p2); push3(p3, t.p3);
+      push3(n1, t.n1); push3(n2, t.n2); push3(n3, t.n3);
+      const double bb[6] = {t.bbox.min.x, t.bbox.min.y, t.bbox.min.z, t.bbox.max.x, t.bbox.max.y, t.bbox.max.z};
+      bbox.insert(bbox.end(), bb, bb + 6);
+      // the same key material_id dedupes by: exact bits
+      const Material& m = t.material;
+      double raw[7 + 3 + 3 + 16] = {m.ambient,      m.diffuse,          m.specular,     m.shininess,    m.reflectivity,
+                                    m.transparency, m.refractive_index, m.pattern.c1.x, m.pattern.c1.y, m.pattern.c1.z,
+                                    m.pattern.c2.x, m.pattern.c2.y,     m.pattern.c2.z};
+      std::memcpy(raw + 13, m.pattern.inv.d, sizeof(double) * 16);
+      std::string key((const char*)raw, sizeof(raw));
+      key.push_back((char)m.pattern.kind);
+      auto it = palette_index.find(key);
+      if (it == palette_index.end()) {
+        it = palette_index.emplace(key, (uint32_t)rec.palette.size()).first;
+        rec.palette.push_back(m);
+      }
+      mat[i] = it->second;
+    }
+    rt_mesh_desc d;
+    std::memset(&d, 0, sizeof(d));
+    d.n_tris = (uint32_t)n;
+    d.shape = shape.data();
+    d.p1 = p1.data(); d.p2 = p2.data(); d.p3 = p3.data();
+    d.n1 = n1.data(); d.n2 = n2.data(); d.n3 = n3.data();
+    d.bbox = bbox.data();
+    d.material = mat.data();
+    d.n_palette = (uint32_t)rec.palette.size();
+    if (create(&d, &rec.handle) != 0) {
+      g_err = "rt_mesh_create failed (see rt_last_error)";
+      return -1;
+    }
+    c.mesh_id = (int)b->meshes.size();
+    c.mesh_posed = false;
+    c.mesh_pending.clear();
+    c.children.clear();  // (box and primitive count stay: the proxy stands for the group)
+    b->meshes.push_back(std::move(rec));
+    made++;
+  }
+  return made;
+}
+
+int rts_extract_meshes(void* vb, uint32_t min_tris, void* create_fn, void* pose_fn, void* destroy_fn) {
+  Builder* b = (Builder*)vb;
+  if (!create_fn || !pose_fn || !destroy_fn) {
+    g_err = "rts_extract_meshes needs rt_mesh_create, rt_mesh_pose and rt_mesh_destroy";
+    return -1;
+  }
+  b->mesh_pose = (rt_mesh_pose_fn)pose_fn;
+  b->mesh_destroy = (rt_mesh_destroy_fn)destroy_fn;
+  return extract_in(b, *b->root, min_tris ? min_tris : 1, (rt_mesh_create_fn)create_fn);
+}
+
+int rts_mesh_count(void* vb) { return (int)((Builder*)vb)->meshes.size(); }
 
 }  // extern "C"

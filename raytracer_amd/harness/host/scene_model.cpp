@@ -378,6 +378,9 @@ ObjectPtr Object::clone() const {
   o->bbox = bbox;
   o->primitive_count_ = primitive_count_;
   o->csg_op = csg_op;
+  o->mesh_id = mesh_id;
+  o->mesh_posed = mesh_posed;
+  o->mesh_pending = mesh_pending;
   for (const auto& c : children) o->children.push_back(c->clone());
   if (left) o->left = left->clone();
   if (right) o->right = right->clone();
@@ -430,7 +433,14 @@ static void triangle_derive(Object& o) {  // triangle.rs:34-47 / smooth_triangle
   }
 }
 
+thread_local MeshPoseHook mesh_pose_hook = nullptr;
+thread_local void* mesh_pose_user = nullptr;
+
 void Object::recalculate_bbox() {
+  if (kind == OBJ_GROUP && mesh_id >= 0) {  // the children are on the device: their union comes from there
+    if (mesh_pose_hook) mesh_pose_hook(*this, mesh_pose_user);
+    return;
+  }
   if (kind == OBJ_GROUP) {  // group.rs:230-235
     bbox = BBox();
     for (const auto& c : children) bbox.add_bbox(c->bbox);
@@ -485,6 +495,7 @@ void Object::transform(const Mat4& m) {
     }
   } else if (kind == OBJ_GROUP) {  // group.rs:263-270
     for (auto& c : children) c->transform(m);
+    if (mesh_id >= 0) mesh_pending.push_back(m);  // (the children of a mesh proxy are transformed on the device)
     bbox = bbox.transformed(m);
   } else {  // csg.rs:157-163
     left->transform(m);

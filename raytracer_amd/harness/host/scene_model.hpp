@@ -149,6 +149,13 @@ struct Object {
   int csg_op = 0;
   ObjectPtr left, right;
 
+  // --- proxy of a device-resident mesh (include/rtcore.h rt_mesh): a group whose children (all triangles) live on the GPU.
+  // It keeps the group's box and primitive count, so everything above it — animate, build_bvh, flatten — treats it as the
+  // group it stands for; the matrices it receives are collected and applied on the device (mesh_pose_hook).
+  int mesh_id = -1;
+  bool mesh_posed = false;
+  std::vector<Mat4> mesh_pending;  // Transform::transform calls since the base pose, in order (group.rs:263-270)
+
   ObjectPtr clone() const;
   size_t primitive_count() const;
   void transform(const Mat4& m);                               // Transform for Object (object.rs:77-85)
@@ -175,5 +182,11 @@ ObjectPtr parse_obj_model(const std::string& source, std::string& err);         
 struct Light {
   V3 position, intensity;
 };
+
+// Poses the mesh behind a proxy group on the device with proxy.mesh_pending and stores the group's recalculate_bbox
+// (group.rs:230-235) in proxy.bbox.  Set per thread by the C-ABI layer (scene_capi.cpp) around animate / flatten.
+using MeshPoseHook = bool (*)(Object& proxy, void* user);
+extern thread_local MeshPoseHook mesh_pose_hook;
+extern thread_local void* mesh_pose_user;
 
 }  // namespace rts

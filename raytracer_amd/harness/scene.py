@@ -239,8 +239,10 @@ class SceneBuilder:
     """`SceneBuilder` (scene.rs:57-147) over an arena of object handles."""
 
     def __init__(self):
+        import threading
         self._L = N.scene_lib()
         self._b = self._L.rts_new()
+        self.mesh_lock = threading.Lock()  # held from flatten_frame to rt_scene_create when the builder has device meshes
 
     def __del__(self):
         try:
@@ -310,6 +312,21 @@ class SceneBuilder:
 
     def add_light(self, position, intensity):
         self._L.rts_add_light(self._b, N.dptr(position), N.dptr(intensity))
+
+    def extract_meshes(self, min_tris: int = 64) -> int:
+        """Device-side per-frame scene preparation (include/rtcore.h rt_mesh): every group of at least
+        min_tris plain triangles moves to the GPU and stays in the tree as a proxy.  From here on `flatten` / `flatten_frame`
+        pose those groups on the device (rt_mesh_pose) and emit RT_REF_MESH references; rt_scene_create builds their
+        subtrees there.  Call once, after the scene is complete.  A builder with meshes prepares ONE frame at a time
+        (`mesh_lock`): pose and scene creation of a mesh must not interleave between frames."""
+        core = N.core_lib()
+        fn = lambda f: C.cast(f, C.c_void_p)
+        made = self._check(self._L.rts_extract_meshes(self._b, int(min_tris), fn(core.rt_mesh_create), fn(core.rt_mesh_pose),
+                                                      fn(core.rt_mesh_destroy)))
+        return made
+
+    def mesh_count(self) -> int:
+        return int(self._L.rts_mesh_count(self._b))
 
     def animation_cycle_duration(self) -> float:
         return float(self._L.rts_animation_cycle_duration_s(self._b))

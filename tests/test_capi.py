@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared_functions():
         assert hasattr(lib, name), f"librtcore.so does not export {name}"
     lib.rt_abi_version.restype = ctypes.c_uint32
-    assert lib.rt_abi_version() == 2
+    assert lib.rt_abi_version() == 3
     lib.rt_tile_count.restype = ctypes.c_uint32
     lib.rt_tile_count.argtypes = [ctypes.c_uint32] * 4
     assert lib.rt_tile_count(800, 800, 0, 1) == 10000 and lib.rt_tile_count(20, 9, 1, 4) == 2  # 3x2 tiles: part 1 of 4 owns tiles {1, 5}
