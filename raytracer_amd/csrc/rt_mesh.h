@@ -251,9 +251,11 @@ __global__ __launch_bounds__(RT_MESH_BLOCK) void acc_reset_kernel(MeshDev M) {
 
 // Candidate plane i of axis a of a group with box bb: `self.bounding_box.min + bbox_len_vec * coef` (group.rs:91-97)
 __device__ __forceinline__ double candidate_pos(const double* bb, int a, int i) {
+  // (selects, not indexed loads: a box held in registers stays there when the axis is a run-time value)
+  const double lo = a == 0 ? bb[0] : (a == 1 ? bb[1] : bb[2]), hi = a == 0 ? bb[3] : (a == 1 ? bb[4] : bb[5]);
   const double coef = ((double)i + 1.) / (5. + 1.);
-  const double len = bb[a + 3] - bb[a];
-  return bb[a] + coef * len;  // Vector * f64 is `rhs * self.x` (vector.rs:136-146)
+  const double len = hi - lo;
+  return lo + coef * len;  // Vector * f64 is `rhs * self.x` (vector.rs:136-146)
 }
 
 // Class of a centre coordinate among the 5 candidate planes of its axis: k = the first plane it lies below (5: none).  The
@@ -266,41 +268,50 @@ __device__ __forceinline__ bool centre_class(const double* bb, int a, double c, 
   return mask == ((0x1Fu << k) & 0x1Fu);
 }
 
-// Every child of an open group of this level adds its box and count to its class on each axis.
+// Groups of at most RT_MESH_SERIAL children are summed by the one thread that also chooses their split (choose_kernel): no
+// atomics at all, and the deep levels of a tree hold thousands of such groups.  Larger groups: every child adds its box and
+// count to its class on each axis — first in LDS, in the accumulators of the (at most RT_MESH_SLOTS) groups a block of 256
+// consecutive positions can meet, then one atomic per class and block: device-wide atomics are served at the memory side, a
+// few per nanosecond whatever the address, and one per child and class (0.5 M per level of a 23 000-triangle model) was half
+// of the build's time.
+#ifndef RT_MESH_SERIAL
+#define RT_MESH_SERIAL 16u
+#endif
+#define RT_MESH_SLOTS (RT_MESH_BLOCK / (RT_MESH_SERIAL + 1u) + 2u)
+#define RT_MESH_CHOOSE_POS 64u                                            // positions a block of choose_kernel looks after
+#define RT_MESH_CHOOSE_WINDOW (RT_MESH_CHOOSE_POS + RT_MESH_SERIAL)   // ... and holds in LDS
 __global__ __launch_bounds__(RT_MESH_BLOCK) void bin_kernel(MeshDev M, uint32_t cur, uint32_t level) {
   if (M.ctrl->active[level] == 0u) return;
-  __shared__ unsigned long long sh_mn[RT_MESH_ACC_PER_SEG][3], sh_mx[RT_MESH_ACC_PER_SEG][3];
-  __shared__ uint32_t sh_cnt[RT_MESH_ACC_PER_SEG];
-  __shared__ uint32_t sh_seg, sh_mixed;
+  __shared__ unsigned long long sh_mn[RT_MESH_SLOTS][RT_MESH_ACC_PER_SEG][3], sh_mx[RT_MESH_SLOTS][RT_MESH_ACC_PER_SEG][3];
+  __shared__ uint32_t sh_cnt[RT_MESH_SLOTS][RT_MESH_ACC_PER_SEG];
+  __shared__ uint32_t sh_key[RT_MESH_SLOTS];
   const uint32_t p = blockIdx.x * RT_MESH_BLOCK + threadIdx.x;
-  if (threadIdx.x < RT_MESH_ACC_PER_SEG) {
+  for (uint32_t i = threadIdx.x; i < RT_MESH_SLOTS * RT_MESH_ACC_PER_SEG; i += RT_MESH_BLOCK) {
+    const uint32_t sl = i / RT_MESH_ACC_PER_SEG, c = i % RT_MESH_ACC_PER_SEG;
     for (int k = 0; k < 3; k++) {
-      sh_mn[threadIdx.x][k] = RT_MESH_KEY_POS_INF;
-      sh_mx[threadIdx.x][k] = RT_MESH_KEY_NEG_INF;
+      sh_mn[sl][c][k] = RT_MESH_KEY_POS_INF;
+      sh_mx[sl][c][k] = RT_MESH_KEY_NEG_INF;
     }
-    sh_cnt[threadIdx.x] = 0u;
+    sh_cnt[sl][c] = 0u;
   }
-  if (threadIdx.x == 0) {
-    sh_seg = RT_NONE;
-    sh_mixed = 0u;
-  }
+  if (threadIdx.x < RT_MESH_SLOTS) sh_key[threadIdx.x] = RT_NONE;
   __syncthreads();
   uint32_t s = RT_NONE;
   bool open = false;
   if (p < M.n) {
     s = M.seg_of[cur][p];
     const Seg& r = M.segs[s];
-    open = r.state == SEG_OPEN && r.level == level;
+    open = r.state == SEG_OPEN && r.level == level && r.end - s > RT_MESH_SERIAL;
   }
-  // a block whose open children all belong to ONE group (the large groups of the top levels) adds up in LDS first: atomics on
-  // one address are served one after the other
   if (open) {
-    const uint32_t old = atomicCAS(&sh_seg, RT_NONE, s);
-    if (old != RT_NONE && old != s) sh_mixed = 1u;
-  }
-  __syncthreads();
-  const bool in_lds = sh_mixed == 0u;
-  if (open) {
+    uint32_t slot = RT_MESH_SLOTS;  // (a block meets at most RT_MESH_SLOTS groups of more than RT_MESH_SERIAL children)
+    for (uint32_t i = 0; i < RT_MESH_SLOTS; i++) {
+      const uint32_t old = atomicCAS(&sh_key[i], RT_NONE, s);
+      if (old == RT_NONE || old == s) {
+        slot = i;
+        break;
+      }
+    }
     const uint32_t elem = M.order[cur][p];
     double gb[6], bb[6];
     for (int k = 0; k < 6; k++) {
@@ -315,15 +326,15 @@ __global__ __launch_bounds__(RT_MESH_BLOCK) void bin_kernel(MeshDev M, uint32_t 
     for (int a = 0; a < 3; a++) {
       uint32_t k;
       if (!centre_class(gb, a, M.ctr[3 * (size_t)elem + a], k)) atomicOr(&M.ctrl->status, (uint32_t)MESH_STATUS_UNORDERED);
-      const uint32_t slot = (uint32_t)a * RT_MESH_CLASSES + k;
-      if (in_lds) {
+      const uint32_t c = (uint32_t)a * RT_MESH_CLASSES + k;
+      if (slot < RT_MESH_SLOTS) {
         for (int j = 0; j < 3; j++) {
-          atomicMin(&sh_mn[slot][j], kmn[j]);
-          atomicMax(&sh_mx[slot][j], kmx[j]);
+          atomicMin(&sh_mn[slot][c][j], kmn[j]);
+          atomicMax(&sh_mx[slot][c][j], kmx[j]);
         }
-        atomicAdd(&sh_cnt[slot], 1u);
+        atomicAdd(&sh_cnt[slot][c], 1u);
       } else {
-        Acc* acc = M.acc + (size_t)s * RT_MESH_ACC_PER_SEG + slot;
+        Acc* acc = M.acc + (size_t)s * RT_MESH_ACC_PER_SEG + c;
         for (int j = 0; j < 3; j++) {
           atomicMin(&acc->mn[j], kmn[j]);
           atomicMax(&acc->mx[j], kmx[j]);
@@ -333,13 +344,15 @@ __global__ __launch_bounds__(RT_MESH_BLOCK) void bin_kernel(MeshDev M, uint32_t 
     }
   }
   __syncthreads();
-  if (in_lds && sh_seg != RT_NONE && threadIdx.x < RT_MESH_ACC_PER_SEG && sh_cnt[threadIdx.x] != 0u) {
-    Acc* acc = M.acc + (size_t)sh_seg * RT_MESH_ACC_PER_SEG + threadIdx.x;
+  for (uint32_t i = threadIdx.x; i < RT_MESH_SLOTS * RT_MESH_ACC_PER_SEG; i += RT_MESH_BLOCK) {
+    const uint32_t sl = i / RT_MESH_ACC_PER_SEG, c = i % RT_MESH_ACC_PER_SEG;
+    if (sh_key[sl] == RT_NONE || sh_cnt[sl][c] == 0u) continue;
+    Acc* acc = M.acc + (size_t)sh_key[sl] * RT_MESH_ACC_PER_SEG + c;
     for (int j = 0; j < 3; j++) {
-      atomicMin(&acc->mn[j], sh_mn[threadIdx.x][j]);
-      atomicMax(&acc->mx[j], sh_mx[threadIdx.x][j]);
+      atomicMin(&acc->mn[j], sh_mn[sl][c][j]);
+      atomicMax(&acc->mx[j], sh_mx[sl][c][j]);
     }
-    atomicAdd(&acc->count, sh_cnt[threadIdx.x]);
+    atomicAdd(&acc->count, sh_cnt[sl][c]);
   }
 }
 
@@ -368,68 +381,186 @@ __device__ __forceinline__ double half_area(const double* mn, const double* mx) 
   return x_len * y_len + y_len * z_len + z_len * x_len;
 }
 
-// One thread per open group of this level: choose_split (group.rs:87-108) over the 15 candidates, the sah_cost test
-// (group.rs:153-156), and the two new groups of split (group.rs:131-143, 157-166).
+// Both sides of candidate plane i of axis a of the group [p, r.end) (calculate_split_cost, group.rs:109-124).  A small
+// group (bin_kernel skipped it): straight from its children, as the reference does — from the block's LDS copy, or from
+// memory for the children beyond the block.  Otherwise from the classes bin_kernel accumulated: left = classes 0..i.
+__device__ __forceinline__ void candidate_sides(const MeshDev& M, uint32_t cur, const Seg& r, uint32_t p, int a, int i, bool small, uint32_t block0,
+                                                const double (*sh_bb)[6], const double (*sh_ctr)[3], Side& left, Side& right) {
+  // (sh_bb / sh_ctr hold positions [block0, block0 + RT_MESH_CHOOSE_WINDOW))
+  side_reset(left);
+  side_reset(right);
+  if (!small) {
+    // (all six classes are fetched before any is looked at; an empty class is the identity of min / max, so none is skipped)
+    unsigned long long kmn[RT_MESH_CLASSES][3], kmx[RT_MESH_CLASSES][3];
+    uint32_t cnt[RT_MESH_CLASSES];
+    const Acc* acc = M.acc + (size_t)p * RT_MESH_ACC_PER_SEG + (uint32_t)a * RT_MESH_CLASSES;
+#pragma unroll
+    for (uint32_t k = 0; k < RT_MESH_CLASSES; k++) {
+      for (int j = 0; j < 3; j++) {
+        kmn[k][j] = acc[k].mn[j];
+        kmx[k][j] = acc[k].mx[j];
+      }
+      cnt[k] = acc[k].count;
+    }
+#pragma unroll
+    for (uint32_t k = 0; k < RT_MESH_CLASSES; k++) {
+      const bool to_left = k <= (uint32_t)i;
+      for (int j = 0; j < 3; j++) {
+        const double mn = dunkey(kmn[k][j]), mx = dunkey(kmx[k][j]);
+        left.mn[j] = to_left ? fmin(mn, left.mn[j]) : left.mn[j];
+        left.mx[j] = to_left ? fmax(mx, left.mx[j]) : left.mx[j];
+        right.mn[j] = to_left ? right.mn[j] : fmin(mn, right.mn[j]);
+        right.mx[j] = to_left ? right.mx[j] : fmax(mx, right.mx[j]);
+      }
+      left.count += to_left ? cnt[k] : 0u;
+      right.count += to_left ? 0u : cnt[k];
+    }
+    return;
+  }
+  const double pos = candidate_pos(r.bb, a, i);
+  for (uint32_t q = p; q < r.end; q++) {
+    double c, bb[6];
+    if (q - block0 < RT_MESH_CHOOSE_WINDOW) {
+      c = sh_ctr[q - block0][a];
+      for (int j = 0; j < 6; j++) bb[j] = sh_bb[q - block0][j];
+    } else {  // (never for a small group that starts in this block: the window reaches RT_MESH_SERIAL positions past it)
+      const uint32_t elem = M.order[cur][q];
+      c = M.ctr[3 * (size_t)elem + a];
+      for (int j = 0; j < 6; j++) bb[j] = M.pbb[6 * (size_t)elem + j];
+    }
+    const bool below = c < pos;  // group.rs:117
+    for (int j = 0; j < 3; j++) {  // add_bounding_box: both corners to both extremes (bounding_box.rs:111-117)
+      const double mn = below ? left.mn[j] : right.mn[j], mx = below ? left.mx[j] : right.mx[j];
+      const double nmn = fmin(bb[j + 3], fmin(bb[j], mn)), nmx = fmax(bb[j + 3], fmax(bb[j], mx));
+      left.mn[j] = below ? nmn : left.mn[j];
+      left.mx[j] = below ? nmx : left.mx[j];
+      right.mn[j] = below ? right.mn[j] : nmn;
+      right.mx[j] = below ? right.mx[j] : nmx;
+    }
+    left.count += below ? 1u : 0u;
+    right.count += below ? 0u : 1u;
+  }
+}
+
+// choose_split (group.rs:87-108) over the 15 candidates, the sah_cost test (group.rs:153-156), and the two new groups of
+// split (group.rs:131-143, 157-166), for every open group of this level.  The 15 candidates of a group are dealt to up to 15
+// threads — those of the group's first positions, which have nothing else to do —, each of which keeps the best of its own in
+// the reference's order (positions outer, axes inner, strict <); the group's first thread then takes the best of those
+// (smallest cost, ties to the earlier candidate: what the reference's single loop keeps) and makes the split.
+#define RT_MESH_HELPERS 15u
+__device__ __forceinline__ void choose_tail(const MeshDev& M, uint32_t cur, uint32_t level, const Seg& r, uint32_t p, bool small, uint32_t helpers,
+                                            uint32_t lanes, uint32_t block0, const double (*sh_bb)[6], const double (*sh_ctr)[3], const double* sh_cost,
+                                            const uint32_t* sh_cand, uint32_t* sh_opened, uint32_t* sh_max_leaf);
+// A block of 256 threads looks after RT_MESH_CHOOSE_POS = 64 positions, four threads per position (wavefront g holds thread g
+// of every position): a deep level has thousands of small groups and little else, and with one thread per position the
+// whole level ran on 368 wavefronts of long serial work, a third of the GPU's SIMDs with one wavefront each.
 __global__ __launch_bounds__(RT_MESH_BLOCK) void choose_kernel(MeshDev M, uint32_t cur, uint32_t level) {
   if (M.ctrl->active[level] == 0u) return;
-  const uint32_t p = blockIdx.x * RT_MESH_BLOCK + threadIdx.x;
-  if (p >= M.n || M.seg_of[cur][p] != p) return;
-  Seg r = M.segs[p];
-  if (r.state != SEG_OPEN || r.level != level) return;
-  // left[i][a] = classes 0..i of axis a, right[i][a] = classes i+1..5: both sides of candidate plane i
-  Side left[5][3], right[5][3];
-  for (int a = 0; a < 3; a++) {
-    Side cls[RT_MESH_CLASSES];
-    for (uint32_t k = 0; k < RT_MESH_CLASSES; k++) {
-      Acc* acc = M.acc + (size_t)p * RT_MESH_ACC_PER_SEG + (uint32_t)a * RT_MESH_CLASSES + k;
-      for (int j = 0; j < 3; j++) {
-        cls[k].mn[j] = dunkey(acc->mn[j]);
-        cls[k].mx[j] = dunkey(acc->mx[j]);
-        acc->mn[j] = RT_MESH_KEY_POS_INF;  // (left empty for the group that starts here next)
-        acc->mx[j] = RT_MESH_KEY_NEG_INF;
+  // the block's children (and the RT_MESH_SERIAL positions behind them) in LDS, box and centre: what the small groups are summed
+  // from, instead of a chain of dependent global loads per child
+  __shared__ double sh_bb[RT_MESH_CHOOSE_WINDOW][6];
+  __shared__ double sh_ctr[RT_MESH_CHOOSE_WINDOW][3];
+  __shared__ double sh_cost[RT_MESH_BLOCK];
+  __shared__ uint32_t sh_cand[RT_MESH_BLOCK];
+  const uint32_t block0 = blockIdx.x * RT_MESH_CHOOSE_POS, g = threadIdx.x / RT_MESH_CHOOSE_POS, t = block0 + threadIdx.x % RT_MESH_CHOOSE_POS;
+  for (uint32_t i = threadIdx.x; i < RT_MESH_CHOOSE_WINDOW * 9u; i += RT_MESH_BLOCK) {  // one f64 per thread and turn
+    const uint32_t pos = block0 + i / 9u, k = i % 9u;
+    if (pos >= M.n) continue;
+    const uint32_t elem = M.order[cur][pos];
+    if (k < 6u) sh_bb[i / 9u][k] = M.pbb[6 * (size_t)elem + k];
+    else sh_ctr[i / 9u][k - 6u] = M.ctr[3 * (size_t)elem + (k - 6u)];
+  }
+  uint32_t p = RT_NONE;  // the group this thread's position belongs to
+  if (t < M.n) p = M.seg_of[cur][t];
+  __syncthreads();
+  Seg r;
+  bool open = false;
+  if (p != RT_NONE && p >= block0) {  // (a group that starts in an earlier block is that block's)
+    r = M.segs[p];
+    open = r.state == SEG_OPEN && r.level == level;
+  }
+  const bool small = open && r.end - p <= RT_MESH_SERIAL;
+  // the group's positions in this block, four threads each: its helpers, RT_MESH_HELPERS at most
+  const uint32_t lanes = open ? min(r.end, block0 + RT_MESH_CHOOSE_POS) - p : 0u;
+  const uint32_t helpers = min(lanes * (RT_MESH_BLOCK / RT_MESH_CHOOSE_POS), RT_MESH_HELPERS);
+  const uint32_t h = open ? g * lanes + (t - p) : RT_NONE;
+  double my_cost = INFINITY;
+  uint32_t my_cand = 0u;
+  if (open && h < helpers)
+    for (uint32_t cand = h; cand < 15u; cand += helpers) {  // cand = 3 i + a: the reference's order
+      Side l, rt;
+      candidate_sides(M, cur, r, p, (int)(cand % 3u), (int)(cand / 3u), small, block0, sh_bb, sh_ctr, l, rt);
+      const double cost = (l.count == 0u || rt.count == 0u) ? INFINITY
+                                                            : half_area(l.mn, l.mx) * (double)l.count + half_area(rt.mn, rt.mx) * (double)rt.count;
+      if (cost < my_cost) {
+        my_cost = cost;
+        my_cand = cand;
       }
-      cls[k].count = acc->count;
-      acc->count = 0u;
     }
-    Side run;
-    side_reset(run);
-    for (int i = 0; i < 5; i++) {
-      side_add(run, cls[i]);
-      left[i][a] = run;
+  sh_cost[threadIdx.x] = my_cost;
+  sh_cand[threadIdx.x] = my_cand;
+  // what the block's groups add to the build's counters goes through LDS: atomics on ONE address are served one after the
+  // other (~10 ns each), and a deep level has thousands of groups
+  __shared__ uint32_t sh_opened, sh_max_leaf;
+  if (threadIdx.x == 0) {
+    sh_opened = 0u;
+    sh_max_leaf = 0u;
+  }
+  __syncthreads();
+  if (open && h == 0u) choose_tail(M, cur, level, r, p, small, helpers, lanes, block0, sh_bb, sh_ctr, sh_cost, sh_cand, &sh_opened, &sh_max_leaf);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    if (sh_opened) {
+      if (level + 1u >= RT_MESH_MAX_LEVELS) atomicOr(&M.ctrl->status, (uint32_t)MESH_STATUS_TOO_DEEP);
+      else atomicAdd(&M.ctrl->active[level + 1u], sh_opened);
     }
-    side_reset(run);
-    for (int i = 4; i >= 0; i--) {
-      side_add(run, cls[i + 1]);
-      right[i][a] = run;
+    if (sh_max_leaf) atomicMax(&M.ctrl->max_leaf, sh_max_leaf);
+  }
+}
+
+// The group's first thread: the best of the helpers' candidates, the sah_cost test, the split.
+__device__ __forceinline__ void choose_tail(const MeshDev& M, uint32_t cur, uint32_t level, const Seg& r, uint32_t p, bool small, uint32_t helpers,
+                                            uint32_t lanes, uint32_t block0, const double (*sh_bb)[6], const double (*sh_ctr)[3], const double* sh_cost,
+                                            const uint32_t* sh_cand, uint32_t* sh_opened, uint32_t* sh_max_leaf) {
+  double best_cost = INFINITY;
+  uint32_t best_cand = 0u;
+  for (uint32_t k = 0; k < helpers; k++) {  // helper k = thread k / lanes of position p + k % lanes
+    const uint32_t tid = (k / lanes) * RT_MESH_CHOOSE_POS + (p - block0) + k % lanes;
+    const double c = sh_cost[tid];
+    const uint32_t cand = sh_cand[tid];
+    if (c < best_cost || (c == best_cost && c < INFINITY && cand < best_cand)) {
+      best_cost = c;
+      best_cand = cand;
     }
   }
-  int best_axis = 0, best_i = 0;
-  double best_pos = 0.0, best_cost = INFINITY;
-  for (int i = 0; i < 5; i++)
-    for (int a = 0; a < 3; a++) {  // group.rs:93-105: positions outer, axes inner, strict <
-      const Side &l = left[i][a], &rt = right[i][a];
-      const double cost = (l.count == 0u || rt.count == 0u)
-                              ? INFINITY
-                              : half_area(l.mn, l.mx) * (double)l.count + half_area(rt.mn, rt.mx) * (double)rt.count;
-      if (cost < best_cost) {
-        best_cost = cost;
-        best_axis = a;
-        best_i = i;
-        best_pos = candidate_pos(r.bb, a, i);
+  const int best_axis = (int)(best_cand % 3u), best_i = (int)(best_cand / 3u);
+  const double best_pos = candidate_pos(r.bb, best_axis, best_i);
+  const bool serial = small;
+  auto reset_acc = [&]() {  // the accumulators are left empty for the group that starts here next
+    if (serial) return;
+    for (uint32_t k = 0; k < RT_MESH_ACC_PER_SEG; k++) {
+      Acc* acc = M.acc + (size_t)p * RT_MESH_ACC_PER_SEG + k;
+      for (int j = 0; j < 3; j++) {
+        acc->mn[j] = RT_MESH_KEY_POS_INF;
+        acc->mx[j] = RT_MESH_KEY_NEG_INF;
       }
+      acc->count = 0u;
     }
+  };
   const uint32_t size = r.end - p;
   const double sah = half_area(r.bb, r.bb + 3) * (double)size;  // ObjectGroup::sah_cost (group.rs:220-222)
   Ctrl* c = M.ctrl;
-  atomicMax(&c->max_level, level);
   uint32_t* parent_slot = r.parent == RT_NONE ? nullptr : &M.bins[r.parent & 0x7FFFFFFFu].child[r.parent >> 31];
   if (best_cost >= sah) {  // group.rs:154-156: the children stay as they are
+    reset_acc();
     M.segs[p].state = SEG_LEAF;
     if (parent_slot) *parent_slot = RT_MESH_CHILD_LEAF;
-    atomicMax(&c->max_leaf, size);
+    atomicMax(sh_max_leaf, size);
     return;
   }
-  const Side &l = left[best_i][best_axis], &rt = right[best_i][best_axis];
+  Side l, rt;
+  candidate_sides(M, cur, r, p, best_axis, best_i, small, block0, sh_bb, sh_ctr, l, rt);
+  reset_acc();
   const uint32_t m = p + l.count;
   if (parent_slot) *parent_slot = m;
   else c->root_split = m;
@@ -468,10 +599,7 @@ __global__ __launch_bounds__(RT_MESH_BLOCK) void choose_kernel(MeshDev M, uint32
     M.segs[start] = ch;
   }
   M.bins[m] = b;
-  if (opened) {
-    if (level + 1u >= RT_MESH_MAX_LEVELS) atomicOr(&c->status, (uint32_t)MESH_STATUS_TOO_DEEP);
-    else atomicAdd(&c->active[level + 1u], opened);
-  }
+  if (opened) atomicAdd(sh_opened, opened);
 }
 
 // "centre below the chosen plane" (group.rs:136) for the child at position p of a group that splits this level.

@@ -1277,7 +1277,7 @@ int mesh_build(rt_mesh* m, const mesh::MeshOut& out, bool built, uint32_t* level
   for (;;) {
     for (; level < target; level++) {
       hipLaunchKernelGGL(mesh::bin_kernel, dim3(grid), dim3(RT_MESH_BLOCK), 0, st, M, cur, level);
-      hipLaunchKernelGGL(mesh::choose_kernel, dim3(grid), dim3(RT_MESH_BLOCK), 0, st, M, cur, level);
+      hipLaunchKernelGGL(mesh::choose_kernel, dim3((m->n + RT_MESH_CHOOSE_POS - 1u) / RT_MESH_CHOOSE_POS), dim3(RT_MESH_BLOCK), 0, st, M, cur, level);
       hipLaunchKernelGGL(mesh::count_kernel, dim3(grid), dim3(RT_MESH_BLOCK), 0, st, M, cur, level);
       hipLaunchKernelGGL(mesh::scatter_kernel, dim3(grid), dim3(RT_MESH_BLOCK), 0, st, M, cur, level);
       cur ^= 1u;
@@ -1297,7 +1297,10 @@ int mesh_build(rt_mesh* m, const mesh::MeshOut& out, bool built, uint32_t* level
   }
   m->acc_clean = true;
   m->cur = cur;
-  m->last_levels = m->h_ctrl->max_level + 2u;  // (levels 0..max_level split or stopped; their children are one level further)
+  uint32_t max_level = 0;  // the deepest level that held an open group
+  for (uint32_t l = 0; l < RT_MESH_MAX_LEVELS; l++)
+    if (m->h_ctrl->active[l]) max_level = l;
+  m->last_levels = max_level + 2u;  // (levels 0..max_level split or stopped; their children are one level further)
   *levels_out = m->last_levels;
   *max_leaf_out = m->h_ctrl->max_leaf;
   return RT_OK;

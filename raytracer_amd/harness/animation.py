@@ -78,13 +78,22 @@ class AnimationRenderer:
 
         device = torch.cuda.current_device()
 
+        builder = self.setup.builder
+        on_device = builder.mesh_count() > 0  # builder.extract_meshes(): transform + build_bvh of the models run on the GPU
+
         def prepare(i: int):  # worker thread: host preparation, then the upload (rt_scene_create)
             torch.cuda.set_device(device)  # HIP's current device is per thread: upload where the render thread renders
-            t0 = _time.perf_counter()
-            flat = self.setup.builder.flatten_frame(self.frame_time(i))
-            t1 = _time.perf_counter()
-            scene = R.DeviceScene(flat)
-            del flat
+            if on_device:  # a posed mesh belongs to one frame until its scene exists (include/rtcore.h): one frame at a time
+                builder.mesh_lock.acquire()
+            try:
+                t0 = _time.perf_counter()
+                flat = builder.flatten_frame(self.frame_time(i))
+                t1 = _time.perf_counter()
+                scene = R.DeviceScene(flat)
+                del flat
+            finally:
+                if on_device:
+                    builder.mesh_lock.release()
             return scene, t1 - t0, _time.perf_counter() - t1
 
         wall0 = _time.perf_counter()

@@ -205,8 +205,10 @@ def test_unbuilt_and_tiny_meshes():
         rng = np.random.default_rng(5)
         tris = []
         for i in range(70):
-            c = rng.uniform(-1, 1, 3)
+            c = rng.uniform(-0.7, 0.7, 3)
             pts = (c[None, :] + rng.uniform(-0.3, 0.3, (3, 3))).reshape(-1)
+            if i < 2:  # the group's box is exactly [-1, 1]^3: its centre is the spheres' centre, no candidate plane separates them
+                pts[0:3] = (-1., -1., -1.) if i == 0 else (1., 1., 1.)
             tris.append(sb.primitive(N.TRIANGLE, S.Material.with_color((0.2, 0.7, 0.3)), tri=list(pts)))
         sb.add_object(sb.group(tris))
         for k in range(3):  # three more children, all overlapping the mesh: no split of the root is cheaper than none
