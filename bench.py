@@ -241,6 +241,54 @@ def main():
             R.render(flat, cam, opt, want_stats=False)
             one_shot_ms = (time.perf_counter() - t1) * 1e3
 
+    one_shot_u8_ms = None
+    if world == 1 and not args.no_one_shot:
+        # the same through rt_render_u8: quantised on the device (color.rs:55-66), 3 bytes per pixel come back instead of 24
+        for _ in range(2):
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            R.render_u8(flat, cam, opt)
+            one_shot_u8_ms = (time.perf_counter() - t1) * 1e3
+
+    # What 8 GPUs will cost, measured on this one (no scaling number is claimed: the driver measures that when it has a node):
+    # each of the 8 cyclic parts of the frame rendered alone, as rank p of 8 would (rt_render_tiles_device), then the
+    # un-interleave of the 8 gathered parts.  predicted = slowest part + the gather over xGMI (estimate) + assemble.
+    parts8 = None
+    if world == 1 and not args.no_one_shot:
+        n8 = D.tile_count(w, h, 0, 8)
+        all8 = torch.zeros((8, n8 * 64 * 3), dtype=torch.float64, device="cuda")
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+        ms_part = []
+        for p in range(8):
+            best = None
+            for _ in range(3):  # (the first render of a part sizes the workspace; the next ones are what a rank's frames cost)
+                ev[0].record()
+                scene.render_tiles(cam, opt, p, 8, all8[p].data_ptr(), stream)
+                ev[1].record()
+                torch.cuda.synchronize()
+                t = ev[0].elapsed_time(ev[1])
+                best = t if best is None else min(best, t)
+            ms_part.append(best)
+        img8 = torch.empty((h, w, 3), dtype=torch.float64, device="cuda")
+        ms_asm = None
+        for _ in range(2):
+            ev[0].record()
+            R.assemble_tiles(w, h, 8, n8, all8.data_ptr(), img8.data_ptr(), stream)
+            ev[1].record()
+            torch.cuda.synchronize()
+            ms_asm = ev[0].elapsed_time(ev[1])
+        same = bool(torch.equal(img8, out))
+        part_bytes = n8 * 64 * 3 * 8
+        xgmi_gbs = 100.0  # assumed achieved rate of ONE xGMI link (153 GB/s peak each; the 7 senders use 7 links side by side)
+        ms_gather = part_bytes / (xgmi_gbs * 1e9) * 1e3
+        parts8 = {"ms_part_max": max(ms_part), "ms_part_mean": sum(ms_part) / 8, "ms_assemble": ms_asm,
+                  "ms_gather_estimate": ms_gather, "gather_bytes_per_rank": part_bytes, "gather_bytes_per_rank_u8": part_bytes // 8,
+                  "assumed_xgmi_GBs_per_link": xgmi_gbs, "predicted_8gpu_ms": max(ms_part) + ms_gather + ms_asm,
+                  "assembled_equals_whole_frame": same,
+                  "note": "measured on ONE GPU: each cyclic part alone + the un-interleave; the gather is an estimate; peer copies "
+                          "and the RCCL gather have never run on two devices"}
+        del all8, img8
+
     def mean(key):
         return sum(p[key] for p in per_step) / len(per_step)
 
@@ -304,7 +352,10 @@ def main():
                        "reflect": tot["rays_reflect"], "refract": tot["rays_refract"],
                        "shadow_rays_not_traced_light_behind_surface": tot["rays_shadow_culled"],
                        "pipeline": "single kernel" if opt.pipeline else "streamed", "host_scene_prep_s": round(t_prep, 2),
-                       "one_shot_ms": one_shot_ms},
+                       "one_shot_ms": one_shot_ms, "one_shot_u8_ms": one_shot_u8_ms,
+                       "part_of_8_ms": None if parts8 is None else {"max": parts8["ms_part_max"], "mean": parts8["ms_part_mean"]},
+                       "predicted_8gpu_ms": None if parts8 is None else parts8["predicted_8gpu_ms"],
+                       "eight_gpu_prediction": parts8},
             # The trace kernels walk a ~17 MB scene that lives in L2 / Infinity Cache: HBM is not what bounds them, the
             # vector units are (VALU issue under SIMD divergence).  So the roofline is priced against the FP64 vector peak
             # — algorithmic f64 operations of the reference's arithmetic per launch / the launch's duration — which cannot

@@ -255,6 +255,13 @@ int rt_device_count(void);       /* number of usable gfx950 devices, <0 on error
 int rt_render(const rt_scene_desc* scene, const rt_camera* camera, const rt_options* options,
               double* out_rgb, rt_stats* stats /* nullable */);
 
+/* The same render with the image quantised on the device: `Color::as_scaled_values` (src/math/color.rs:55-66) per channel,
+ * i.e. what `Image::as_u8_rgb` (image.rs:84-89) hands the PNG / PPM / video encoders.  out_rgb8: caller-owned HOST buffer,
+ * width*height*3 bytes, row-major, r,g,b.  3 bytes per pixel instead of 24 come back over PCIe (and, with n_devices > 1, travel
+ * between the devices).  The bytes equal as_scaled_values of rt_render's f64 pixels exactly. */
+int rt_render_u8(const rt_scene_desc* scene, const rt_camera* camera, const rt_options* options,
+                 uint8_t* out_rgb8, rt_stats* stats /* nullable */);
+
 /* ---- resident-scene API (what an animation loop or a multi-GPU driver uses) ----------------- */
 typedef struct rt_scene rt_scene; /* opaque: the scene re-laid-out in device memory */
 
@@ -339,6 +346,11 @@ int rt_render_tiles_device(const rt_scene* scene, const rt_camera* camera, const
  * padded buffers); 0 means the blocks are tightly concatenated (block p holds rt_tile_count(.., p, n_parts) tiles). */
 int rt_assemble_tiles_device(uint32_t width, uint32_t height, uint32_t n_parts, uint32_t part_stride_tiles,
                              const double* d_tiles_all_parts, double* d_out_rgb, void* hip_stream);
+
+/* The same for tiles that were quantised before the gather (rt_quantize_device on each part's packed tiles: the order of the
+ * values is the same, 1 byte each): packed u8 tiles of all parts -> row-major width*height*3 bytes. */
+int rt_assemble_tiles_u8_device(uint32_t width, uint32_t height, uint32_t n_parts, uint32_t part_stride_tiles,
+                                const uint8_t* d_tiles_all_parts, uint8_t* d_out_rgb8, void* hip_stream);
 
 /* Whole image, row-major, into DEVICE memory (n_parts == 1 path; no assembly step needed). */
 int rt_render_device(const rt_scene* scene, const rt_camera* camera, const rt_options* options,

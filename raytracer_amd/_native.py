@@ -167,6 +167,8 @@ def core_lib() -> C.CDLL:
     L.rt_last_error.restype = C.c_char_p
     L.rt_device_count.restype = C.c_int
     L.rt_render.argtypes = [sp, cp, op, _pd, stp]
+    L.rt_render_u8.argtypes = [sp, cp, op, C.POINTER(C.c_uint8), stp]
+    L.rt_assemble_tiles_u8_device.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
     L.rt_scene_create.argtypes = [sp, C.POINTER(C.c_void_p)]
     L.rt_scene_destroy.argtypes = [C.c_void_p]
     L.rt_release_cached_memory.argtypes = []

@@ -157,9 +157,10 @@ __global__ __launch_bounds__(64, REFORDER ? 2 : RT_WAVES_PER_EU) void render_til
 }
 
 // Packed tiles of all parts (part-major, as an all-gather delivers them) -> row-major image.
+template <class T>  // f64 pixels, or u8 ones (rt_quantize_device of the packed tiles: an eighth of the bytes through the gather)
 __global__ __launch_bounds__(256) void assemble_tiles_kernel(uint32_t width, uint32_t height, uint32_t n_parts, uint32_t part_stride,
-                                                             uint32_t tiles_x, uint32_t n_tiles, const double* __restrict__ tiles,
-                                                             double* __restrict__ out) {
+                                                             uint32_t tiles_x, uint32_t n_tiles, const T* __restrict__ tiles,
+                                                             T* __restrict__ out) {
   size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;  // one thread per (tile, lane)
   if (gid >= (size_t)n_tiles * 64) return;
   uint32_t tile = (uint32_t)(gid / 64), lane = (uint32_t)(gid % 64);
@@ -171,8 +172,8 @@ __global__ __launch_bounds__(256) void assemble_tiles_kernel(uint32_t width, uin
   uint32_t px = (tile % tiles_x) * RT_TILE_DIM + (lane & 7u);
   uint32_t py = (tile / tiles_x) * RT_TILE_DIM + (lane >> 3);
   if (px >= width || py >= height) return;
-  const double* src = tiles + ((base + k) * 64 + lane) * 3;
-  double* dst = out + ((size_t)py * width + px) * 3;
+  const T* src = tiles + ((base + k) * 64 + lane) * 3;
+  T* dst = out + ((size_t)py * width + px) * 3;
   dst[0] = src[0];
   dst[1] = src[1];
   dst[2] = src[2];
@@ -441,6 +442,14 @@ struct StageBuffer {
     size = n;
     return p;
   }
+  // Room for n bytes without moving: tables that are filled IN PLACE (stage_inplace) hold pointers into the buffer.
+  bool reserve(size_t n) {
+    if (n <= cap) return true;
+    const size_t keep = size;
+    if (!resize(n)) return false;
+    size = keep;
+    return true;
+  }
   ~StageBuffer() { std::free(p); }
 };
 
@@ -514,6 +523,7 @@ struct rt_scene {
   std::vector<std::pair<size_t, size_t>> reserved; // [begin, end) of the arena image that the DEVICE fills (mesh parts of tables): not uploaded
   const uint32_t* mesh_mat_map = nullptr;          // the meshes' palettes as this scene's material indices / flags (rt_mesh.h MeshOut)
   const uint8_t* mesh_mat_flags = nullptr;
+  const char* stage_base = nullptr;                // the staging buffer while tables are filled in place: it must not move
   size_t table_bytes[7] = {};                      // rt_scene_debug_table: tri_isect, tri_norm, prim_rank, prim_info, entries, nodes, prim_flags
   int device = 0;
   void* noalloc_scratch = nullptr;          // this device's copy of the `scratch` array (rt_render_device_noalloc)
@@ -591,6 +601,21 @@ size_t stage_bytes(rt_scene* sc, const void* data, size_t bytes, void* pointer_t
   sc->bytes += bytes + tail;
   return off;
 }
+// A table that is filled where it will be uploaded from (no vector of its own: a fresh 20-MB vector costs its page faults,
+// and then a copy).  rt_scene_create has reserved the buffer's capacity, so the pointer stays valid until commit_arena.
+template <class T>
+T* stage_inplace(rt_scene* sc, size_t count, const T** out, size_t tail_elements = 0) {
+  StageBuffer& st = *sc->stage;
+  const size_t bytes = count * sizeof(T), tail = tail_elements * sizeof(T);
+  size_t off = (st.size + 255) & ~(size_t)255, len = std::max<size_t>(bytes, 16);
+  char* p = st.resize(off + std::max(len, bytes + tail));
+  if (!p) return nullptr;
+  if (!bytes) std::memset(p + off, 0, len);
+  if (tail) sc->reserved.push_back({off + bytes, off + bytes + tail});
+  sc->fixups.push_back({off, (void*)out});
+  sc->bytes += bytes + tail;
+  return (T*)(p + off);
+}
 template <class T>
 int upload(rt_scene* sc, const std::vector<T>& host, const T** out, size_t tail_elements = 0) {
   stage_bytes(sc, host.data(), host.size() * sizeof(T), (void*)out, tail_elements * sizeof(T));
@@ -601,6 +626,7 @@ int upload(rt_scene* sc, const std::vector<T>& host, const T** out, size_t tail_
 int commit_arena(rt_scene* sc) {
   StageBuffer& st = *sc->stage;
   if (!st.p) return fail(RT_ERR_DEVICE, "out of host memory while staging the scene tables");
+  if (sc->stage_base && sc->stage_base != st.p) return fail(RT_ERR_HOST, "internal error: the staging buffer moved under tables filled in place");
   size_t need = (st.size + 255) & ~(size_t)255;
   sc->arena = g_device_pool.take(need, sc->device, &sc->arena_cap);
   if (!sc->arena) return fail(RT_ERR_DEVICE, "hipMalloc of the scene tables (" + std::to_string(need >> 20) + " MiB) failed");
@@ -974,7 +1000,12 @@ uint32_t build_group(const rt_scene_desc* d, FastLayout& L, uint32_t g, uint32_t
 // node; while a slot is free, the inner child with the largest box is replaced by ITS two children (its own box is then
 // never tested: the children's boxes are tested directly).  Also finds the deepest the traversal stack can get: a
 // visit of a node with k children pushes at most k - 1 of them.
-void fold_nodes(FastLayout& L) {
+struct FoldTodo {
+  uint32_t bin, wide, held;  // binary node to fold, its wide node (index into `nodes`), stack entries held while inside it
+};
+// Folds the subtrees on `todo` into `nodes` until none is left — or, limit > 0, until at least `limit` subtrees wait (which the
+// caller then hands to threads).
+void fold_some(FastLayout& L, std::vector<DevNode>& nodes, std::vector<FoldTodo>& todo, uint32_t& stack_need, size_t limit) {
   struct Slot {
     double bb[6];
     uint32_t ref;
@@ -985,20 +1016,13 @@ void fold_nodes(FastLayout& L) {
     double a = dx * dy + dy * dz + dz * dx;
     return a == a ? a : INFINITY;
   };
-  L.nodes.clear();
-  L.nodes.emplace_back();
-  struct Todo {
-    uint32_t bin, wide, held;  // binary node to fold, its wide node, stack entries held while inside it
-  };
-  std::vector<Todo> todo{{0u, 0u, 0u}};
-  L.stack_need = 0;
   std::vector<Slot> slots;  // (one allocation for all nodes)
   slots.reserve(2 * RT_NODE_WIDTH);
-  L.nodes.reserve(L.bin.size() / 2 + 16);
   while (!todo.empty()) {
+    if (limit && todo.size() >= limit) return;
     // (RT_LDS_NODES: the first nodes are numbered breadth-first — the top levels of the tree —, the rest depth-first)
-    const bool breadth_first = L.nodes.size() < (size_t)RT_LDS_NODES;
-    Todo t = breadth_first ? todo.front() : todo.back();
+    const bool breadth_first = nodes.size() < (size_t)RT_LDS_NODES;
+    FoldTodo t = breadth_first ? todo.front() : todo.back();
     if (breadth_first) todo.erase(todo.begin());
     else todo.pop_back();
     slots.clear();
@@ -1029,7 +1053,7 @@ void fold_nodes(FastLayout& L) {
     DevNode n;
     std::memset(&n, 0, sizeof(n));
     uint32_t held = t.held + (slots.empty() ? 0u : (uint32_t)slots.size() - 1u);
-    if (held > L.stack_need) L.stack_need = held;
+    if (held > stack_need) stack_need = held;
 #if RT_QNODE
     {
       double boxes[RT_NODE_WIDTH][6];
@@ -1049,8 +1073,8 @@ void fold_nodes(FastLayout& L) {
       set_node_box(n, i, slots[i].bb);
 #endif
       if (inner(slots[i].ref)) {
-        uint32_t wide = (uint32_t)L.nodes.size();
-        L.nodes.emplace_back();
+        uint32_t wide = (uint32_t)nodes.size();
+        nodes.emplace_back();
         n.ref[i] = RT_MAKE_FREF(RT_FREF_INNER, 0, wide);
         todo.push_back({slots[i].ref & RT_FREF_INDEX_MASK, wide, held});
       } else {
@@ -1058,21 +1082,68 @@ void fold_nodes(FastLayout& L) {
         if (RT_IS_MESH_MARKER(slots[i].ref)) L.mesh_held[slots[i].ref & RT_FREF_INDEX_MASK] = held;
       }
     }
-    L.nodes[t.wide] = n;
+    nodes[t.wide] = n;
+  }
+}
+
+// The whole tree: the top of it on this thread until a handful of subtrees wait, then those on up to four threads, each into
+// a table of its own (its node 0 = the subtree's root, whose place in L.nodes is taken already), appended to L.nodes
+// afterwards with their references moved (6.2 -> 2 ms for dragons.yml's 40 000 wide nodes).
+void fold_nodes(FastLayout& L) {
+  L.nodes.clear();
+  L.nodes.emplace_back();
+  L.nodes.reserve(L.bin.size() / 2 + 16);
+  std::vector<FoldTodo> todo{{0u, 0u, 0u}};
+  L.stack_need = 0;
+  const bool threaded = L.bin.size() >= 16384 && RT_LDS_NODES == 0 && !RT_QNODE;
+  fold_some(L, L.nodes, todo, L.stack_need, threaded ? 8 : 0);
+  if (todo.empty() || !L.error.empty()) return;
+  const size_t n_sub = todo.size();
+  std::vector<std::vector<DevNode>> local(n_sub);
+  std::vector<uint32_t> need(n_sub, 0u);
+  std::atomic<size_t> next{0};
+  auto work = [&] {
+    for (size_t k = next.fetch_add(1); k < n_sub; k = next.fetch_add(1)) {
+      local[k].emplace_back();
+      std::vector<FoldTodo> mine{{todo[k].bin, 0u, todo[k].held}};
+      fold_some(L, local[k], mine, need[k], 0);
+    }
+  };
+  {
+    std::vector<std::thread> workers;
+    JoinAll join{workers};
+    for (int t = 1; t < 4; t++) workers.emplace_back(work);
+    work();
+    for (std::thread& t : workers) t.join();
+  }
+  for (size_t k = 0; k < n_sub; k++) {
+    const uint32_t base = (uint32_t)L.nodes.size();  // local node i >= 1 -> base + i - 1
+    for (DevNode& n : local[k])
+      for (int c = 0; c < RT_NODE_WIDTH; c++)
+        if (n.ref[c] != RT_FREF_NONE && (n.ref[c] >> RT_FREF_KIND_SHIFT) == RT_FREF_INNER)
+          n.ref[c] = RT_MAKE_FREF(RT_FREF_INNER, 0, base + (n.ref[c] & RT_FREF_INDEX_MASK) - 1u);
+    L.nodes[todo[k].wide] = local[k][0];
+    L.nodes.insert(L.nodes.end(), local[k].begin() + 1, local[k].end());
+    L.stack_need = std::max(L.stack_need, need[k]);
   }
 }
 
 uint32_t mesh_tris(const rt_scene_desc* d, uint32_t k) { return d->mesh[k]->n; }
 
 bool build_fast_layout(const rt_scene_desc* d, FastLayout& L) {
-  assign_ranks(d, L.prim_rank, L.mesh_rank0);
+  // (L.prim_rank / L.mesh_rank0 — assign_ranks — are filled by rt_scene_create's own thread, beside this one)
   L.mesh_held.assign(d->n_meshes, 0u);
   L.prim_tri.assign(d->n_prims, RT_NONE);
   if (const char* e = getenv("RT_LEAF_TRIS")) L.leaf_tris = (uint32_t)std::min(std::max(atoi(e), 1), (int)RT_FREF_LEAF_MAX);
   L.bin.reserve((size_t)d->n_nodes + 2);
   L.bin.emplace_back();  // node 0: the synthetic root
+  const bool debug_timing = std::getenv("RT_DEBUG_TIMING") != nullptr;
+  auto t0 = std::chrono::steady_clock::now();
   uint32_t root = build_group(d, L, 0, 1);
   if (!L.error.empty()) return false;
+  if (debug_timing)
+    fprintf(stderr, "[rtcore]   (layout thread) binary tree of %zu nodes: %.2f ms\n", L.bin.size(),
+            std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
   BinNode n;
   std::memset(&n, 0, sizeof(n));
   std::memcpy(n.bb[0], d->node_bbox, sizeof(n.bb[0]));
@@ -1081,6 +1152,9 @@ bool build_fast_layout(const rt_scene_desc* d, FastLayout& L) {
   L.bin[0] = n;
   fold_nodes(L);
   if (!L.error.empty()) return false;
+  if (debug_timing)
+    fprintf(stderr, "[rtcore]   (layout thread) + fold into %zu wide nodes: %.2f ms\n", L.nodes.size(),
+            std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
   // triangles outside triangle-only leaves (mixed leaves, CSG operands) still need a slot in the triangle tables
   for (uint32_t i = 0; i < d->n_prims; i++) {
     uint8_t sh = d->prim_shape[i];
@@ -1934,13 +2008,19 @@ void add_stats(rt_stats* total, const rt_stats& s) {
 // process, animation_renderer.rs:109-122): a host thread per device creates the scene there, renders the device's cyclic
 // share of the 8x8 tiles into a packed buffer and copies it into the gather buffer on the first device; that device
 // un-interleaves (assemble_tiles_kernel) and the image is downloaded from it.
-int render_on_devices(const std::vector<int>& devs, const rt_scene_desc* desc, const rt_camera* cam, const rt_options* opt, double* out_rgb,
-                      rt_stats* stats) {
+int assemble_tiles(uint32_t width, uint32_t height, uint32_t n_parts, uint32_t part_stride_tiles, const void* d_tiles, void* d_out, bool u8,
+                   hipStream_t st);
+// u8: every device quantises its packed tiles (Color::as_scaled_values, color.rs:55-66) before they travel: 3 bytes per pixel
+// instead of 24 through the peer copies, the assembly and the download; out is then width * height * 3 bytes.
+int render_on_devices(const std::vector<int>& devs, const rt_scene_desc* desc, const rt_camera* cam, const rt_options* opt, void* out_rgb,
+                      bool u8, rt_stats* stats) {
   const uint32_t n = (uint32_t)devs.size();
   int rc = check_camera_options(cam, opt);
   if (rc) return rc;
   const uint32_t n_max = rt_tile_count(cam->width, cam->height, 0, n);
-  const size_t part_bytes = (size_t)n_max * 64 * 3 * sizeof(double), image_bytes = (size_t)cam->width * cam->height * 3 * sizeof(double);
+  const size_t px_bytes = u8 ? 1 : sizeof(double);
+  const size_t part_values = (size_t)n_max * 64 * 3, render_bytes = part_values * sizeof(double);
+  const size_t part_bytes = part_values * px_bytes, image_bytes = (size_t)cam->width * cam->height * 3 * px_bytes;
   struct PoolBlock {
     void* p = nullptr;
     size_t cap = 0;
@@ -1982,8 +2062,9 @@ int render_on_devices(const std::vector<int>& devs, const rt_scene_desc* desc, c
         } guard{sc};
         PoolBlock local;
         local.device = devs[k];
-        local.p = g_device_pool.take(part_bytes ? part_bytes : 16, devs[k], &local.cap);
+        local.p = g_device_pool.take((render_bytes ? render_bytes : 16) + (u8 ? part_values : 0), devs[k], &local.cap);
         if (!local.p) return fail(RT_ERR_DEVICE, "hipMalloc of a device's tile buffer failed");
+        void* send = u8 ? (void*)((char*)local.p + render_bytes) : local.p;  // (the u8 copy of the tiles sits behind the f64 ones)
         hipStream_t st = nullptr;
         HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
         struct StreamGuard {
@@ -1992,10 +2073,15 @@ int render_on_devices(const std::vector<int>& devs, const rt_scene_desc* desc, c
         } sguard{st};
         std::memset(&part_stats[k], 0, sizeof(rt_stats));
         r = launch_render(sc, cam, opt, k, n, 1, (double*)local.p, st, stats ? &part_stats[k] : nullptr);
+        if ((r == RT_OK || r == RT_ERR_OVERFLOW) && u8 && part_values) {
+          hipLaunchKernelGGL(quantize_kernel, dim3((unsigned)((part_values + 255) / 256)), dim3(256), 0, st, (const double*)local.p, (uint64_t)part_values,
+                             (uint8_t*)send);
+          if (hipGetLastError() != hipSuccess) r = fail(RT_ERR_DEVICE, "quantize launch failed");
+        }
         if (r == RT_OK || r == RT_ERR_OVERFLOW) {
           char* dst = (char*)gather.p + (size_t)k * part_bytes;
-          hipError_t e = devs[k] == devs[0] ? hipMemcpyAsync(dst, local.p, part_bytes, hipMemcpyDeviceToDevice, st)
-                                            : hipMemcpyPeerAsync(dst, devs[0], local.p, devs[k], part_bytes, st);
+          hipError_t e = devs[k] == devs[0] ? hipMemcpyAsync(dst, send, part_bytes, hipMemcpyDeviceToDevice, st)
+                                            : hipMemcpyPeerAsync(dst, devs[0], send, devs[k], part_bytes, st);
           if (e != hipSuccess) r = fail(RT_ERR_DEVICE, std::string("copy of a device's tiles to the first device failed: ") + hipGetErrorString(e));
         }
         hipError_t e = hipStreamSynchronize(st);
@@ -2014,7 +2100,7 @@ int render_on_devices(const std::vector<int>& devs, const rt_scene_desc* desc, c
   for (uint32_t k = 0; k < n; k++)
     if (rcs[k] && rcs[k] != RT_ERR_OVERFLOW) return fail(rcs[k], "device " + std::to_string(devs[k]) + ": " + errs[k]);
   HIP_TRY(hipSetDevice(devs[0]));
-  rc = rt_assemble_tiles_device(cam->width, cam->height, n, n_max, (const double*)gather.p, (double*)image.p, nullptr);
+  rc = assemble_tiles(cam->width, cam->height, n, n_max, gather.p, image.p, u8, nullptr);
   if (rc) return rc;
   if (download_image(out_rgb, image.p, image_bytes) != hipSuccess) return fail(RT_ERR_DEVICE, "download of the image failed");
   if (stats) {
@@ -2025,6 +2111,24 @@ int render_on_devices(const std::vector<int>& devs, const rt_scene_desc* desc, c
     if (rcs[k] == RT_ERR_OVERFLOW) return fail(RT_ERR_OVERFLOW, "device " + std::to_string(devs[k]) + ": " + errs[k]);
   return RT_OK;
 }
+
+int assemble_tiles(uint32_t width, uint32_t height, uint32_t n_parts, uint32_t part_stride_tiles, const void* d_tiles, void* d_out, bool u8,
+                   hipStream_t st) {
+  if (!d_tiles || !d_out || n_parts == 0 || width == 0 || height == 0) return fail(RT_ERR_INVALID_ARGUMENT, "bad arguments to rt_assemble_tiles_device");
+  uint32_t tiles_x;
+  uint32_t n_tiles = tiles_total(width, height, &tiles_x);
+  size_t threads = (size_t)n_tiles * 64;
+  if (u8)
+    hipLaunchKernelGGL(assemble_tiles_kernel<uint8_t>, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, width, height, n_parts,
+                       part_stride_tiles, tiles_x, n_tiles, (const uint8_t*)d_tiles, (uint8_t*)d_out);
+  else
+    hipLaunchKernelGGL(assemble_tiles_kernel<double>, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, width, height, n_parts,
+                       part_stride_tiles, tiles_x, n_tiles, (const double*)d_tiles, (double*)d_out);
+  HIP_TRY(hipGetLastError());
+  return RT_OK;
+}
+
+int render_one_shot(const rt_scene_desc* scene_desc, const rt_camera* camera, const rt_options* options, void* out, bool u8, rt_stats* stats);
 
 }  // namespace
 
@@ -2084,18 +2188,43 @@ int rt_scene_create(const rt_scene_desc* d, rt_scene** out) try {
     return fail(RT_ERR_UNSUPPORTED, "the BVH needs a traversal stack of " + std::to_string(need) + " entries; the device limit is " +
                                         std::to_string(RT_STACK_MAX));
 
-  // child records: record 0 = root, then node i's children at 1 + node_child_begin[i]
-  std::vector<DevEntry> entries((size_t)d->n_child_refs + 1);
+  std::unique_ptr<rt_scene> owner(new rt_scene());  // (destroyed on every path but the last)
+  rt_scene* sc = owner.get();
+  t_stage.size = 0;
+  sc->stage = &t_stage;
+  (void)hipGetDevice(&sc->device);
+  uint64_t mesh_tris_total = 0;
+  for (uint32_t k = 0; k < d->n_meshes; k++) mesh_tris_total += d->mesh[k]->n;
+  {  // an upper bound of the arena image: the big tables are filled in place, so the buffer must not move (stage_inplace)
+    const size_t P = d->n_prims, R = d->n_child_refs, T = (size_t)mesh_tris_total;
+    size_t cap = (R + d->n_nodes + 16) * sizeof(DevNode) + R * (4 + sizeof(DevLeafRec)) + ((size_t)d->n_csgs + 1) * sizeof(DevCsg2Rec) +
+                 (R + 2 + 2 * (size_t)d->n_csgs) * sizeof(DevEntry) + P * (4 + 16 + 4 + 1) + (size_t)d->n_xforms * 128 +
+                 P * (RT_TRI_STRIDE + 9) * sizeof(double) + (size_t)d->n_quadrics * 17 + (size_t)d->n_csgs * 10 +
+                 (size_t)d->n_materials * (64 + 1 + 24 + 24 + 128 + 8) + (size_t)d->n_lights * 48 +
+                 T * (2 * sizeof(DevNode) + (RT_TRI_STRIDE + 9) * sizeof(double) + 4 + 16 + 4 + 1 + 3 * sizeof(DevEntry)) + 64 * 1024;
+    if (!t_stage.reserve(cap)) return fail_host("staging the scene tables");
+    sc->stage_base = t_stage.p;
+  }
+
+  // child records: record 0 = root, then node i's children at 1 + node_child_begin[i]; filled in place (20 MB for dragons.yml)
+  size_t n_entries = (size_t)d->n_child_refs + 1;
+  for (uint32_t i = 0; i < d->n_csgs; i++)  // + one record per group that is a CSG operand (below)
+    n_entries += ((d->csg_left[i] >> RT_REF_KIND_SHIFT) == RT_REF_NODE) + ((d->csg_right[i] >> RT_REF_KIND_SHIFT) == RT_REF_NODE);
+  DevEntry* entries = stage_inplace<DevEntry>(sc, n_entries, &sc->dev.entries, 3 * (size_t)mesh_tris_total);
+  if (!entries) return fail_host("staging the scene tables");
+  size_t entries_size = (size_t)d->n_child_refs + 1;
   auto fill_node_fields = [&](DevEntry& e, uint32_t node) {
     std::memcpy(e.bb, d->node_bbox + (size_t)node * 6, sizeof(double) * 6);
     e.begin = 1 + d->node_child_begin[node];
     e.count = d->node_child_begin[node + 1] - d->node_child_begin[node];
   };
-  entries[0].ref = RT_MAKE_REF(RT_REF_NODE, 0);  // (the vector's elements are value-initialised: all zero)
+  std::memset(&entries[0], 0, sizeof(DevEntry));
+  entries[0].ref = RT_MAKE_REF(RT_REF_NODE, 0);
   fill_node_fields(entries[0], 0);
   std::vector<uint32_t> mesh_root_entry(d->n_meshes, 0u);
   for (uint32_t i = 0; i < d->n_child_refs; i++) {
     DevEntry& e = entries[(size_t)i + 1];
+    std::memset(&e, 0, sizeof(e));
     e.ref = d->child_ref[i];
     if ((e.ref >> RT_REF_KIND_SHIFT) == RT_REF_NODE) fill_node_fields(e, e.ref & RT_REF_INDEX_MASK);
     if ((e.ref >> RT_REF_KIND_SHIFT) == RT_REF_MESH) {  // a group for the walk; its child range is written by the device build
@@ -2119,9 +2248,10 @@ int rt_scene_create(const rt_scene_desc* d, rt_scene** out) try {
       std::memset(&e, 0, sizeof(e));
       e.ref = ref;
       fill_node_fields(e, g);
-      (*side)[i] = RT_MAKE_REF(RT_REF_NODE, (uint32_t)entries.size());
-      entries.push_back(e);
+      (*side)[i] = RT_MAKE_REF(RT_REF_NODE, (uint32_t)entries_size);
+      entries[entries_size++] = e;
     }
+  assign_ranks(d, L.prim_rank, L.mesh_rank0);  // (the layout thread does not touch these two)
   lap("entries");
   if (two_threads) layout_thread.join();
   else layout_ok = build_fast_layout(d, L);
@@ -2136,7 +2266,8 @@ int rt_scene_create(const rt_scene_desc* d, rt_scene** out) try {
     uint32_t node0, tri0, prim0, entry_groups0, entry_prims0, mat0;
   };
   std::vector<MeshRange> mesh_range(d->n_meshes);
-  uint64_t mesh_tris_total = 0, mesh_nodes_total = 0, mesh_entries_total = 0;
+  uint64_t mesh_nodes_total = 0, mesh_entries_total = 0;
+  mesh_tris_total = 0;
   {
     for (uint32_t k = 0; k < d->n_meshes; k++) {
       const uint32_t n = d->mesh[k]->n;
@@ -2144,7 +2275,7 @@ int rt_scene_create(const rt_scene_desc* d, rt_scene** out) try {
       r.node0 = (uint32_t)(std::max<size_t>(L.nodes.size(), (size_t)RT_LDS_NODES) + mesh_nodes_total);
       r.tri0 = (uint32_t)(L.n_dev_tris + mesh_tris_total);
       r.prim0 = (uint32_t)(d->n_prims + mesh_tris_total);
-      r.entry_groups0 = (uint32_t)(entries.size() + mesh_entries_total);
+      r.entry_groups0 = (uint32_t)(entries_size + mesh_entries_total);
       r.entry_prims0 = r.entry_groups0 + 2u * n;
       r.mat0 = d->mesh_material_begin[k];
       mesh_tris_total += n;
@@ -2153,24 +2284,28 @@ int rt_scene_create(const rt_scene_desc* d, rt_scene** out) try {
     }
     if (L.nodes.size() + mesh_nodes_total > RT_FREF_INDEX_MASK || L.n_dev_tris + mesh_tris_total > RT_FREF_INDEX_MASK)
       return fail(RT_ERR_UNSUPPORTED, "scene too large for 24-bit node/triangle indices");
-    if (entries.size() + mesh_entries_total > 0xFFFFFFFFull) return fail(RT_ERR_UNSUPPORTED, "scene too large for 32-bit child records");
+    if (entries_size + mesh_entries_total > 0xFFFFFFFFull) return fail(RT_ERR_UNSUPPORTED, "scene too large for 32-bit child records");
     for (DevNode& n : L.nodes)
       for (int c = 0; c < RT_NODE_WIDTH; c++)
         if (RT_IS_MESH_MARKER(n.ref[c])) n.ref[c] = RT_MAKE_FREF(RT_FREF_INNER, 0, mesh_range[n.ref[c] & RT_FREF_INDEX_MASK].node0);
   }
-  std::vector<uint4> prim_info(d->n_prims);
+  uint4* prim_info = stage_inplace<uint4>(sc, d->n_prims, &sc->dev.prim_info, (size_t)mesh_tris_total);
+  if (!prim_info) return fail_host("staging the scene tables");
   for (uint32_t i = 0; i < d->n_prims; i++) {
     bool tri = d->prim_shape[i] == RT_SHAPE_TRIANGLE || d->prim_shape[i] == RT_SHAPE_SMOOTH_TRIANGLE;
     prim_info[i] = make_uint4(d->prim_shape[i], d->prim_material[i], d->prim_xform[i], tri ? L.prim_tri[i] : d->prim_geom[i]);
   }
   // triangle tables in leaf order: [slot][RT_TRI_STRIDE] p1, e1, e2, prim;  [slot][9] n1, n2, n3
-  std::vector<double> tri_isect((size_t)L.n_dev_tris * RT_TRI_STRIDE), tri_norm((size_t)L.n_dev_tris * 9);
-  for (uint32_t i = 0; i < d->n_prims; i++) {
+  double* tri_isect = stage_inplace<double>(sc, (size_t)L.n_dev_tris * RT_TRI_STRIDE, &sc->dev.tri_isect, (size_t)mesh_tris_total * RT_TRI_STRIDE);
+  double* tri_norm = stage_inplace<double>(sc, (size_t)L.n_dev_tris * 9, &sc->dev.tri_norm, (size_t)mesh_tris_total * 9);
+  if (!tri_isect || !tri_norm) return fail_host("staging the scene tables");
+  auto fill_tris = [&](uint32_t from, uint32_t to) {
+  for (uint32_t i = from; i < to; i++) {
     uint32_t slot = L.prim_tri[i];
     if (slot == RT_NONE) continue;
     size_t src = d->prim_geom[i];
-    double* ti = tri_isect.data() + (size_t)slot * RT_TRI_STRIDE;
-    double* tn = tri_norm.data() + (size_t)slot * 9;
+    double* ti = tri_isect + (size_t)slot * RT_TRI_STRIDE;
+    double* tn = tri_norm + (size_t)slot * 9;
     for (int k = 0; k < 3; k++) {
       ti[k] = d->tri_p1[src * 3 + k];
       ti[3 + k] = d->tri_e1[src * 3 + k];
@@ -2183,6 +2318,17 @@ int rt_scene_create(const rt_scene_desc* d, rt_scene** out) try {
     if (d->material[(size_t)d->prim_material[i] * RT_MAT_STRIDE + RT_MAT_TRANSPARENCY] == 0.) bits |= 1ull << RT_TRI_OPAQUE_BIT;
     std::memcpy(ti + 9, &bits, sizeof(bits));
   }
+  };
+  if (d->n_prims >= 32768) {  // (every primitive writes its own slot: four threads, 5 -> 1.5 ms for 140 000 triangles)
+    std::vector<std::thread> fillers;
+    JoinAll join_fillers{fillers};
+    const uint32_t per = (d->n_prims + 3) / 4;
+    for (uint32_t k = 1; k < 4; k++) fillers.emplace_back(fill_tris, std::min(k * per, d->n_prims), std::min((k + 1) * per, d->n_prims));
+    fill_tris(0, std::min(per, d->n_prims));
+    for (std::thread& t : fillers) t.join();
+  } else {
+    fill_tris(0, d->n_prims);
+  }
   std::vector<double> quadric((size_t)d->n_quadrics * 2);
   for (size_t i = 0; i < d->n_quadrics; i++) {
     quadric[i * 2] = d->quadric_y_min[i];
@@ -2191,11 +2337,6 @@ int rt_scene_create(const rt_scene_desc* d, rt_scene** out) try {
 
   if (std::getenv("RT_DEBUG_TIMING"))
     fprintf(stderr, "[rtcore] layout: %.2f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_create).count());
-  std::unique_ptr<rt_scene> owner(new rt_scene());  // (destroyed on every path but the last)
-  rt_scene* sc = owner.get();
-  t_stage.size = 0;
-  sc->stage = &t_stage;
-  (void)hipGetDevice(&sc->device);
   sc->noalloc_scratch = scratch_on_device(sc->device);
   sc->stack_need = need;
 #define UP(vec, field)                                 \
@@ -2266,8 +2407,7 @@ int rt_scene_create(const rt_scene_desc* d, rt_scene** out) try {
     UP(recs, leaf_rec);
   }
   UPT(L.prim_rank, prim_rank, mesh_tris_total);
-  UPT(entries, entries, mesh_entries_total);
-  UPT(prim_info, prim_info, mesh_tris_total);
+  // (entries, prim_info and the triangle tables are in place already: stage_inplace)
   {
     std::vector<uint32_t> v(d->prim_csg_left, d->prim_csg_left + d->n_prims);
     UPT(v, prim_csg_left, mesh_tris_total);
@@ -2302,13 +2442,11 @@ int rt_scene_create(const rt_scene_desc* d, rt_scene** out) try {
     stage_bytes(sc, mat_flags.data(), mat_flags.size(), (void*)&sc->mesh_mat_flags);
   }
   UPA(double, d->xform_inv, (size_t)d->n_xforms * 16, xform_inv);
-  UPT(tri_isect, tri_isect, mesh_tris_total * RT_TRI_STRIDE);
-  UPT(tri_norm, tri_norm, mesh_tris_total * 9);
-  sc->table_bytes[0] = (tri_isect.size() + mesh_tris_total * RT_TRI_STRIDE) * sizeof(double);
-  sc->table_bytes[1] = (tri_norm.size() + mesh_tris_total * 9) * sizeof(double);
+  sc->table_bytes[0] = ((size_t)L.n_dev_tris + mesh_tris_total) * RT_TRI_STRIDE * sizeof(double);
+  sc->table_bytes[1] = ((size_t)L.n_dev_tris + mesh_tris_total) * 9 * sizeof(double);
   sc->table_bytes[2] = (d->n_prims + mesh_tris_total) * sizeof(uint32_t);
   sc->table_bytes[3] = (d->n_prims + mesh_tris_total) * sizeof(uint4);
-  sc->table_bytes[4] = (entries.size() + mesh_entries_total) * sizeof(DevEntry);
+  sc->table_bytes[4] = (entries_size + mesh_entries_total) * sizeof(DevEntry);
   sc->table_bytes[5] = (L.nodes.size() + mesh_nodes_total) * sizeof(DevNode);
   sc->table_bytes[6] = d->n_prims + mesh_tris_total;
   UP(quadric, quadric);
@@ -2634,15 +2772,12 @@ int rt_render_device_noalloc(const rt_scene* scene, const rt_camera* camera, con
 
 int rt_assemble_tiles_device(uint32_t width, uint32_t height, uint32_t n_parts, uint32_t part_stride_tiles,
                              const double* d_tiles_all_parts, double* d_out_rgb, void* hip_stream) try {
-  if (!d_tiles_all_parts || !d_out_rgb || n_parts == 0 || width == 0 || height == 0)
-    return fail(RT_ERR_INVALID_ARGUMENT, "bad arguments to rt_assemble_tiles_device");
-  uint32_t tiles_x;
-  uint32_t n_tiles = tiles_total(width, height, &tiles_x);
-  size_t threads = (size_t)n_tiles * 64;
-  hipLaunchKernelGGL(assemble_tiles_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)hip_stream, width,
-                     height, n_parts, part_stride_tiles, tiles_x, n_tiles, d_tiles_all_parts, d_out_rgb);
-  HIP_TRY(hipGetLastError());
-  return RT_OK;
+  return assemble_tiles(width, height, n_parts, part_stride_tiles, d_tiles_all_parts, d_out_rgb, false, (hipStream_t)hip_stream);
+} RT_NO_UNWIND
+
+int rt_assemble_tiles_u8_device(uint32_t width, uint32_t height, uint32_t n_parts, uint32_t part_stride_tiles,
+                                const uint8_t* d_tiles_all_parts, uint8_t* d_out_rgb8, void* hip_stream) try {
+  return assemble_tiles(width, height, n_parts, part_stride_tiles, d_tiles_all_parts, d_out_rgb8, true, (hipStream_t)hip_stream);
 } RT_NO_UNWIND
 
 int rt_quantize_device(const double* d_rgb, uint64_t n_values, uint8_t* d_out_u8, void* hip_stream) try {
@@ -2716,11 +2851,22 @@ int rt_trace_rays(const rt_scene* scene, const rt_options* options, uint32_t n, 
 } RT_NO_UNWIND
 
 int rt_render(const rt_scene_desc* scene_desc, const rt_camera* camera, const rt_options* options, double* out_rgb, rt_stats* stats) try {
+  return render_one_shot(scene_desc, camera, options, out_rgb, false, stats);
+} RT_NO_UNWIND
+
+int rt_render_u8(const rt_scene_desc* scene_desc, const rt_camera* camera, const rt_options* options, uint8_t* out_rgb8, rt_stats* stats) try {
+  return render_one_shot(scene_desc, camera, options, out_rgb8, true, stats);
+} RT_NO_UNWIND
+
+}  // extern "C"
+
+namespace {
+int render_one_shot(const rt_scene_desc* scene_desc, const rt_camera* camera, const rt_options* options, void* out_rgb, bool u8, rt_stats* stats) {
   if (!out_rgb || !camera) return fail(RT_ERR_INVALID_ARGUMENT, "out_rgb and camera are required");
   if (!scene_desc || !options) return fail(RT_ERR_INVALID_ARGUMENT, "scene and options are required");
   {
     std::vector<int> devs = device_list(options);
-    if (devs.size() > 1) return render_on_devices(devs, scene_desc, camera, options, out_rgb, stats);
+    if (devs.size() > 1) return render_on_devices(devs, scene_desc, camera, options, out_rgb, u8, stats);
   }
   Event e0, e1, e2, e3;  // (destroyed on every path)
   if (stats) {
@@ -2738,8 +2884,9 @@ int rt_render(const rt_scene_desc* scene_desc, const rt_camera* camera, const rt
     ~SceneGuard() { rt_scene_destroy(s); }
   } guard{sc};
   if (stats) HIP_TRY(hipEventRecord(e1.e, 0));
-  // the image: a block of the device pool (an animation through this entry point renders frame after frame)
-  size_t bytes = (size_t)camera->width * camera->height * 3 * sizeof(double);
+  // the image: a block of the device pool (an animation through this entry point renders frame after frame); its u8 copy behind it
+  const size_t n_values = (size_t)camera->width * camera->height * 3;
+  size_t bytes = n_values * sizeof(double);
   struct PoolBlock {
     void* p = nullptr;
     size_t cap = 0;
@@ -2747,14 +2894,20 @@ int rt_render(const rt_scene_desc* scene_desc, const rt_camera* camera, const rt
     ~PoolBlock() { g_device_pool.give(p, cap, device); }
   } image;
   image.device = sc->device;
-  image.p = g_device_pool.take(bytes ? bytes : 16, sc->device, &image.cap);
+  image.p = g_device_pool.take((bytes ? bytes : 16) + (u8 ? n_values : 0), sc->device, &image.cap);
   if (!image.p) return fail(RT_ERR_DEVICE, "hipMalloc(image) failed");
+  uint8_t* image_u8 = (uint8_t*)image.p + bytes;
   // stats == NULL (what the reference-side hook passes): the production kernels, nothing synchronises before the download
   rt_stats local;
   rc = launch_render(sc, camera, options, 0, 1, 0, (double*)image.p, 0, stats ? &local : nullptr);
   if (rc == RT_OK || rc == RT_ERR_OVERFLOW) {
     if (stats) (void)hipEventRecord(e2.e, 0);
-    if (download_image(out_rgb, image.p, bytes) != hipSuccess) rc = fail(RT_ERR_DEVICE, "download of the image failed");
+    if (u8 && n_values) {  // Color::as_scaled_values on the device: 3 bytes per pixel come back instead of 24
+      hipLaunchKernelGGL(quantize_kernel, dim3((unsigned)((n_values + 255) / 256)), dim3(256), 0, 0, (const double*)image.p, (uint64_t)n_values, image_u8);
+      if (hipGetLastError() != hipSuccess) rc = fail(RT_ERR_DEVICE, "quantize launch failed");
+    }
+    if (download_image(out_rgb, u8 ? (const void*)image_u8 : image.p, u8 ? n_values : bytes) != hipSuccess)
+      rc = fail(RT_ERR_DEVICE, "download of the image failed");
     if (!stats && rc == RT_OK) {  // (with stats launch_render has looked already; the download above has waited for the frame)
       uint32_t ovf = 0;
       if (hipMemcpy(&ovf, sc->d_overflow, sizeof(ovf), hipMemcpyDeviceToHost) == hipSuccess && ovf)
@@ -2776,6 +2929,5 @@ int rt_render(const rt_scene_desc* scene_desc, const rt_camera* camera, const rt
   // (the download has waited for the frame: its summary is in; ~rt_scene remembers what it says about this kind of scene)
   absorb_summary(sc);
   return rc;
-} RT_NO_UNWIND
-
-}  // extern "C"
+}
+}  // namespace

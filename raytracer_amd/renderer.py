@@ -108,6 +108,22 @@ def render(flat, camera: N.rt_camera, options: N.rt_options, want_stats: bool = 
     return out, (st.as_dict() if st is not None else None)
 
 
+def render_u8(flat, camera: N.rt_camera, options: N.rt_options, want_stats: bool = False) -> Tuple[np.ndarray, Optional[dict]]:
+    """`Renderer::render` + `Image::as_u8_rgb` (image.rs:84-89) in one `rt_render_u8` call: the image is quantised on the
+    device and 3 bytes per pixel come back.  Returns (rgb8[h, w, 3] u8, stats)."""
+    out = np.zeros((camera.height, camera.width, 3), dtype=np.uint8)
+    st = N.rt_stats() if want_stats else None
+    _check(N.core_lib().rt_render_u8(C.byref(flat.desc), C.byref(camera), C.byref(options),
+                                     out.ctypes.data_as(C.POINTER(C.c_uint8)), C.byref(st) if st is not None else None))
+    return out, (st.as_dict() if st is not None else None)
+
+
+def assemble_tiles_u8(width: int, height: int, n_parts: int, part_stride_tiles: int, d_tiles_ptr: int, d_out_ptr: int,
+                      stream: int = 0):
+    _check(N.core_lib().rt_assemble_tiles_u8_device(width, height, n_parts, part_stride_tiles, C.c_void_p(d_tiles_ptr),
+                                                    C.c_void_p(d_out_ptr), C.c_void_p(stream)))
+
+
 def as_u8_rgb(rgb: np.ndarray) -> np.ndarray:
     """`Color::as_scaled_values` (color.rs:55-66) on the host: round-half-away(clamp(v,0,1)*255), NaN -> 0."""
     v = np.nan_to_num(np.clip(rgb, 0., 1.), nan=0.) * 255.

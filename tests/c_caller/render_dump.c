@@ -18,6 +18,7 @@
 #include "rtcore.h"
 
 typedef int (*rt_render_fn)(const rt_scene_desc*, const rt_camera*, const rt_options*, double*, rt_stats*);
+typedef int (*rt_render_u8_fn)(const rt_scene_desc*, const rt_camera*, const rt_options*, uint8_t*, rt_stats*);
 typedef const char* (*rt_last_error_fn)(void);
 typedef uint32_t (*rt_abi_version_fn)(void);
 
@@ -36,7 +37,7 @@ static void on_progress(uint64_t pixels_done, void* user) {
 }
 
 int main(int argc, char** argv) {
-  if (argc < 4) { fprintf(stderr, "usage: render_dump <librtcore.so> <scene.bin> <out.f64> [progress]\n"); return 2; }
+  if (argc < 4) { fprintf(stderr, "usage: render_dump <librtcore.so> <scene.bin> <out.f64> [progress] [out.u8]\n"); return 2; }
   void* lib = dlopen(argv[1], RTLD_NOW);
   if (!lib) { fprintf(stderr, "dlopen: %s\n", dlerror()); return 2; }
   rt_render_fn render = (rt_render_fn)dlsym(lib, "rt_render");
@@ -109,6 +110,17 @@ int main(int argc, char** argv) {
   FILE* g = fopen(argv[3], "wb");
   if (!g || fwrite(out, sizeof(double), n_values, g) != n_values) { perror(argv[3]); return 2; }
   fclose(g);
+  if (argc > 5) { /* the same frame as the writers' bytes: rt_render_u8 (Image::as_u8_rgb, image.rs:84-89, on the device) */
+    rt_render_u8_fn render_u8 = (rt_render_u8_fn)dlsym(lib, "rt_render_u8");
+    if (!render_u8) { fprintf(stderr, "missing rt_render_u8\n"); return 2; }
+    uint8_t* out8 = (uint8_t*)malloc(n_values);
+    opt.progress = NULL;
+    rc = render_u8(&d, &cam, &opt, out8, NULL);
+    if (rc != 0) { fprintf(stderr, "rt_render_u8 failed: %d: %s\n", rc, last_error()); return 1; }
+    FILE* g8 = fopen(argv[5], "wb");
+    if (!g8 || fwrite(out8, 1, n_values, g8) != n_values) { perror(argv[5]); return 2; }
+    fclose(g8);
+  }
   printf("rendered %ux%u nodes %u prims %u tris %u progress_calls %llu progress_pixels %llu\n", cam.width, cam.height, d.n_nodes, d.n_prims,
          d.n_tris, (unsigned long long)g_calls, (unsigned long long)g_pixels);
   return 0;

@@ -62,9 +62,12 @@ def test_c_caller_image_equals_oracle(tmp_path, name, kw, n_devices):
     import oracle as O
     flat, cam, opt = _load(name, **kw)
     dump_scene(tmp_path / "s.bin", flat, cam, opt, n_devices)
-    r = subprocess.run([EXE, LIB, str(tmp_path / "s.bin"), str(tmp_path / "o.f64"), "progress"], capture_output=True, text=True, timeout=300)
+    r = subprocess.run([EXE, LIB, str(tmp_path / "s.bin"), str(tmp_path / "o.f64"), "progress", str(tmp_path / "o.u8")], capture_output=True,
+                       text=True, timeout=300)
     assert r.returncode == 0, r.stderr
     got = np.fromfile(tmp_path / "o.f64", dtype=np.float64).reshape(cam.height, cam.width, 3)
+    got8 = np.fromfile(tmp_path / "o.u8", dtype=np.uint8).reshape(cam.height, cam.width, 3)
+    assert np.array_equal(got8, O.quantize(got))  # rt_render_u8 == Color::as_scaled_values of rt_render's pixels, through the C-ABI
     want, _ = O.render(flat, cam, opt)
     assert float(np.abs(got - want).max()) < 1e-9
     assert np.array_equal(O.quantize(got), O.quantize(want))

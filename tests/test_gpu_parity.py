@@ -363,6 +363,9 @@ def test_rt_render_over_several_devices_and_progress(monkeypatch):
         seen.clear()
         got, _ = R.render(flat, cam, o, want_stats=False)
         assert np.array_equal(got, want) and sum(seen) == cam.width * cam.height
+        # rt_render_u8: quantised on the device(s) before anything travels; the bytes of Color::as_scaled_values (color.rs:55-66)
+        got8, _ = R.render_u8(flat, cam, o)
+        assert got8.dtype == np.uint8 and np.array_equal(got8, O.quantize(want)), (n_devices, fake)
 
 
 def test_dragon_scene_config2_vs_oracle():

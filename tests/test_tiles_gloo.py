@@ -62,10 +62,14 @@ def _worker(rank, world, port, out_path):
             return D.assemble_tiles_host(w, h, parts)
 
         img = D.gather_frame(local, w, h, rank, world, dist, assemble)
+        # the u8 gather (render_frame_gpu(as_u8=True)): every rank quantises its packed tiles first, 3 bytes per pixel travel
+        local8 = torch.from_numpy(O.quantize(local.numpy()))
+        img8 = D.gather_frame(local8, w, h, rank, world, dist, assemble)
         if rank == 0:
             np.save(out_path, np.stack([img, full]))
+            assert img8.dtype == np.uint8 and np.array_equal(img8, O.quantize(full))
         else:
-            assert img is None
+            assert img is None and img8 is None
         dist.barrier()
     finally:
         dist.destroy_process_group()
