@@ -314,6 +314,15 @@ int rt_mesh_pose(rt_mesh* mesh, uint32_t n_matrices, const double* matrices, dou
  * min(size, capacity) bytes. */
 long long rt_scene_debug_table(const rt_scene* scene, int which, void* out, unsigned long long capacity);
 
+/* Debugging / tests: the traversal's conservative f32 box test beside the exact f64 slab test of the reference
+ * (BoundingBox::intersection_time, bounding_box.rs:192-225) that it stands in for, for n (ray, box, closest-hit-so-far) triples:
+ * origin / direction [n][3] f64, boxes [n][6] f32 (min xyz, max xyz), limit [n] f64 (all HOST arrays); all_t = 1: the container
+ * walk's variant (boxes behind the origin are wanted too).  out[i]: bit 0 the f32 test keeps the box, bit 1 the exact test
+ * does, bit 2 the ray is one production tests exactly anyway (an axis-parallel direction).  The property the renderer rests
+ * on: bit 1 implies bit 0 wherever bit 2 is clear. */
+int rt_debug_box_tests(uint32_t n, const double* origin, const double* direction, const float* boxes, const double* limit, int all_t,
+                       uint8_t* out);
+
 /* Library housekeeping, no counterpart in the reference.  Destroyed scenes leave their device blocks (table arena,
  * render workspace) in a process-wide pool for the next rt_scene_create / render on the same device: an animation makes
  * one scene per frame (animation_renderer.rs:61-66) and would otherwise pay hipMalloc / hipFree, which also

@@ -179,6 +179,7 @@ def core_lib() -> C.CDLL:
     L.rt_mesh_pose.argtypes = [C.c_void_p, C.c_uint32, _pd, _pd]
     L.rt_scene_debug_table.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_ulonglong]
     L.rt_scene_debug_table.restype = C.c_longlong
+    L.rt_debug_box_tests.argtypes = [C.c_uint32, _pd, _pd, C.POINTER(C.c_float), _pd, C.c_int, _pu8]
     L.rt_shutdown.argtypes = []
     L.rt_shutdown.restype = None
     L.rt_tile_count.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]

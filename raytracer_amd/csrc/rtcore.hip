@@ -226,6 +226,30 @@ __global__ __launch_bounds__(64, REFORDER ? 2 : RT_WAVES_PER_EU) void trace_rays
   if (cnt.overflow) atomicOr(overflow_flag, 1u);
 }
 
+// rt_debug_box_tests: the node step's conservative f32 slab test (fast::box_test_f32) beside the exact f64 test it stands in
+// for (fast::box_key_f64: the reference's BoundingBox::intersection_time arithmetic, bounding_box.rs:192-225, on the node's
+// f32 box), one (ray, box, limit) triple per thread.  out: bit 0 the f32 test keeps the box, bit 1 the exact test keeps it,
+// bit 2 the ray takes the exact test in production (an infinite or huge 1 / d component: Trav::odd).
+__global__ __launch_bounds__(256) void debug_box_test_kernel(uint32_t n, const double* __restrict__ origin, const double* __restrict__ dir,
+                                                             const float* __restrict__ boxes, const double* __restrict__ limit, int all_t,
+                                                             uint8_t* __restrict__ out) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  fast::Trav T;
+  const d3 o = mk3(origin[3 * i], origin[3 * i + 1], origin[3 * i + 2]), d = mk3(dir[3 * i], dir[3 * i + 1], dir[3 * i + 2]);
+  fast::trav_start(T, o, d, all_t ? fast::M_CONTAINERS : fast::M_CLOSEST, all_t ? 0. : limit[i]);
+  if (!all_t) {  // (as add_roots leaves them after a hit at `limit`)
+    T.limit = limit[i];
+    T.limf = fast::f32_above(fast::near_limit(limit[i]));
+  }
+  uint32_t raw[6];
+  for (int k = 0; k < 6; k++) raw[k] = __float_as_uint(boxes[6 * (size_t)i + k]);
+  float lo;
+  const bool keep32 = fast::box_test_f32(T, raw, 0, all_t ? -INFINITY : 0.f, 0u, lo);
+  const bool keep64 = (all_t ? fast::box_key_f64<fast::MS_ALL>(T, raw, 0, true, 0u) : fast::box_key_f64<fast::MS_CLOSEST>(T, raw, 0, false, 0u)) != RT_KEY_NONE;
+  out[i] = (keep32 ? 1u : 0u) | (keep64 ? 2u : 0u) | (T.odd ? 4u : 0u);
+}
+
 // ---------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------
@@ -2672,6 +2696,27 @@ int rt_mesh_pose(rt_mesh* m, uint32_t n_matrices, const double* matrices, double
   }
   if (out_bbox6) std::memcpy(out_bbox6, m->bbox, sizeof(m->bbox));
   m->posed = true;
+  return RT_OK;
+} RT_NO_UNWIND
+
+int rt_debug_box_tests(uint32_t n, const double* origin, const double* direction, const float* boxes, const double* limit, int all_t,
+                       uint8_t* out) try {
+  if (!origin || !direction || !boxes || !limit || !out) return fail(RT_ERR_INVALID_ARGUMENT, "bad arguments to rt_debug_box_tests");
+  if (n == 0) return RT_OK;
+  DeviceBuffer b_o, b_d, b_b, b_l, b_out;
+  HIP_TRY(b_o.alloc((size_t)n * 24));
+  HIP_TRY(b_d.alloc((size_t)n * 24));
+  HIP_TRY(b_b.alloc((size_t)n * 24));
+  HIP_TRY(b_l.alloc((size_t)n * 8));
+  HIP_TRY(b_out.alloc(n));
+  HIP_TRY(hipMemcpy(b_o.p, origin, (size_t)n * 24, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(b_d.p, direction, (size_t)n * 24, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(b_b.p, boxes, (size_t)n * 24, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(b_l.p, limit, (size_t)n * 8, hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(debug_box_test_kernel, dim3((n + 255) / 256), dim3(256), 0, 0, n, (const double*)b_o.p, (const double*)b_d.p,
+                     (const float*)b_b.p, (const double*)b_l.p, all_t, (uint8_t*)b_out.p);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpy(out, b_out.p, n, hipMemcpyDeviceToHost));
   return RT_OK;
 } RT_NO_UNWIND
 

@@ -56,6 +56,13 @@ def test_golden_png_full_size(name):
     ref = np.array(Image.open(os.path.join(GOLDEN, "renders", "test", name + ".png")).convert("RGB"))
     diff = np.abs(ref.astype(int) - R.as_u8_rgb(gpu).astype(int)).max(axis=2)
     assert (diff <= 1).mean() >= 0.999, f"{(diff > 1).sum()} pixels off by more than 1 LSB"
+    # and the kernels that ship: stats = NULL (the hook's call) runs the builds WITHOUT counters; their image, and the bytes
+    # of rt_render_u8 (quantised on the device), against the same PNG
+    plain, _ = R.render(rs.builder.flatten(), rs.camera, rs.options(), want_stats=False)
+    assert np.array_equal(plain, gpu)
+    u8, _ = R.render_u8(rs.builder.flatten(), rs.camera, rs.options())
+    diff = np.abs(ref.astype(int) - u8.astype(int)).max(axis=2)
+    assert (diff <= 1).mean() >= 0.999, f"{(diff > 1).sum()} pixels of the counter-free u8 render off by more than 1 LSB"
 
 
 @pytest.mark.parametrize("name", IMAGES)
@@ -694,3 +701,173 @@ def test_timing_mode_reports_kernel_classes():
     parts = sum(st[k] for k in ("ms_trace_closest", "ms_retrace", "ms_shade", "ms_trace_shadow", "ms_combine", "ms_other"))
     # (a batch this small runs level 0's shadow rays on the side stream, beside the other classes: include/rtcore.h, rt_stats)
     assert 0 < parts - st["ms_trace_shadow"] <= st["ms_kernel"] * 1.05 and 0 < st["ms_trace_shadow"] <= st["ms_kernel"] * 1.05
+
+
+# ---- CSG: the reference's truth tables (csg.rs:208-241) realised as geometry and replayed through the device ---------------
+_UNION_ALLOWED = {(True, True, True): False, (True, True, False): True, (True, False, True): False, (True, False, False): True,
+                  (False, True, True): False, (False, True, False): False, (False, False, True): True, (False, False, False): True}
+_DIFFERENCE_ALLOWED = {(True, True, True): False, (True, True, False): True, (True, False, True): False, (True, False, False): True,
+                       (False, True, True): True, (False, True, False): True, (False, False, True): False, (False, False, False): False}
+
+
+def _allowed(op, row):  # csg.rs:208-241, literally (intersection = the negation of union, :226-229)
+    if op == N.CSG_UNION:
+        return _UNION_ALLOWED[row]
+    if op == N.CSG_INTERSECTION:
+        return not _UNION_ALLOWED[row]
+    return _DIFFERENCE_ALLOWED[row]
+
+
+def _slab(sb, z0, z1, colour):
+    """A cube stretched to z in [z0, z1] (x, y in [-1, 1])."""
+    m = S.matrix_from_transformations([S.Transformation.scaling(1., 1., (z1 - z0) / 2.), S.Transformation.translation(0., 0., (z0 + z1) / 2.)])
+    return sb.primitive(N.CUBE, S.Material(S.Pattern(N.P_CONST, colour)), m)
+
+
+@pytest.mark.parametrize("op", [N.CSG_UNION, N.CSG_INTERSECTION, N.CSG_DIFFERENCE])
+def test_csg_truth_tables_on_device(op):
+    """Every row (hit_left, inside_left, inside_right) of is_intersection_allowed (csg.rs:50-65; the tables of its unit tests,
+    csg.rs:208-241) as a configuration of two slabs in which the ray's FIRST intersection ahead is of exactly that kind (the
+    inside flags as filter_intersections holds them when it asks, i.e. after the toggle, csg.rs:92-109): the intersection at
+    t = 1 survives iff the table says so — checked on the oracle's surviving intersections — and the device's colour for the
+    ray equals the oracle's (production kernels and reference-order walk)."""
+    opt = S.make_options(1, 3, True)
+    for row in sorted(_UNION_ALLOWED):
+        hit_left, inside_left, inside_right = row
+        entering = inside_left if hit_left else inside_right       # the hit object's own flag after its toggle
+        other_inside = inside_right if hit_left else inside_left
+        sb = S.SceneBuilder()
+        hit_obj = (0., 2.)                                            # entered at z = 0, left at z = 2
+        other = (-5., 5.) if other_inside else (10., 12.)
+        lz, rz = (hit_obj, other) if hit_left else (other, hit_obj)
+        sb.add_object(sb.csg(op, _slab(sb, *lz, (1., 0.2, 0.2)), _slab(sb, *rz, (0.2, 1., 0.2))))
+        sb.add_light((-3., 4., -20.), (1., 1., 1.))
+        flat = sb.flatten(build_bvh=False)
+        o = (0.3, 0.2, -1. if entering else 1.)                       # the boundary of the hit object lies 1 ahead
+        d = (0., 0., 1.)
+        t, _ = O.intersect_all(flat, o, d)
+        ahead = [float(x) for x in t if x > 0]
+        survives = bool(ahead) and abs(ahead[0] - 1.) < 1e-12
+        assert survives == _allowed(op, row), (op, row, list(t))
+        sc = R.DeviceScene(flat)
+        want = O.color_at(flat, opt, o, d)
+        got = sc.trace_rays(opt, np.array([o]), np.array([d]))[0]
+        ref = sc.trace_rays(_ref_order(opt), np.array([o]), np.array([d]))[0]
+        assert float(np.abs(got - want).max()) < F64_TOL and float(np.abs(ref - want).max()) < F64_TOL, (op, row)
+        sc.close()
+
+
+def test_csg_nested_three_deep_vs_oracle():
+    """CSG objects nested three deep, ((A - B) & C) | D: object.rs:98-104 classifies a hit inside a NESTED CSG operand as
+    "right" (includes only recurses into groups), and every level filters with its own flags."""
+    sb = S.SceneBuilder()
+    red, green, blue = (S.Material(S.Pattern(N.P_CONST, c), reflectivity=0.1) for c in ((1., .3, .3), (.3, 1., .3), (.3, .3, 1.)))
+    a = sb.primitive(N.CUBE, red)
+    b = sb.primitive(N.SPHERE, green, S.matrix_from_transformations([S.Transformation.scaling_uniform(1.3)]))
+    c = sb.primitive(N.SPHERE, blue, S.matrix_from_transformations([S.Transformation.scaling_uniform(1.6)]))
+    dd = sb.primitive(N.CYLINDER, S.Material.glass(), S.matrix_from_transformations([S.Transformation.scaling(0.4, 1., 0.4)]),
+                      y_min=-2., y_max=2., closed=True)
+    inner = sb.csg(N.CSG_DIFFERENCE, a, b)
+    mid = sb.csg(N.CSG_INTERSECTION, inner, c)
+    sb.add_object(sb.csg(N.CSG_UNION, mid, dd))
+    sb.add_object(sb.primitive(N.PLANE, S.Material(S.Pattern(N.P_CHECKERS, (1., 1., 1.), (.3, .3, .3))), translation(0., -2.2, 0.)))
+    sb.add_light((-4., 6., -6.), (1., 1., 1.))
+    flat = sb.flatten()
+    assert flat.desc.n_csgs == 3 and sorted(int(v) for v in flat.array("csg_depth")) == [0, 1, 2]
+    cam = S.make_camera(128, 96, 1.0, S.view_transformation((2.5, 2., -5.), (0., 0., 0.), (0., 1., 0.)))
+    check_against_oracle(flat, cam, S.make_options(2, 5, True))
+    rng = np.random.default_rng(11)
+    origins = rng.uniform(-3, 3, (1024, 3))
+    dirs = rng.normal(size=(1024, 3))
+    dirs /= np.linalg.norm(dirs, axis=1, keepdims=True)
+    opt = S.make_options(1, 4, True)
+    sc = R.DeviceScene(flat)
+    got = sc.trace_rays(opt, origins, dirs)
+    want = np.stack([O.color_at(flat, opt, o, d) for o, d in zip(origins, dirs)])
+    assert float(np.abs(got - want).max()) < F64_TOL
+    sc.close()
+
+
+def test_csg_below_a_group_that_is_a_csg_operand_is_refused_loudly():
+    """The one CSG construction the device does not evaluate (DESIGN.md "Limits"): a CSG object inside a GROUP that is itself
+    a CSG operand.  The reference renders it (csg.rs:113-115 + group.rs:171-201); here rt_scene_create says so — status and
+    message — instead of rendering something else."""
+    sb = S.SceneBuilder()
+    inner = sb.csg(N.CSG_UNION, sb.primitive(N.SPHERE), sb.primitive(N.CUBE, None, translation(0.5, 0., 0.)))
+    grp = sb.group([inner, sb.primitive(N.SPHERE, None, translation(-0.5, 0., 0.))])
+    sb.add_object(sb.csg(N.CSG_DIFFERENCE, grp, sb.primitive(N.SPHERE, None, translation(0., 0.8, 0.))))
+    sb.add_light((-4., 6., -6.), (1., 1., 1.))
+    flat = sb.flatten(build_bvh=False)
+    with pytest.raises(R.RtError) as e:
+        R.DeviceScene(flat)
+    assert e.value.code == -2 and "CSG object inside a group that is a CSG operand" in str(e.value)
+
+
+def test_f32_box_test_never_culls_what_the_exact_test_keeps():
+    """fast::box_test_f32 (the production node step) against the exact f64 slab test of the reference
+    (BoundingBox::intersection_time, bounding_box.rs:192-225, as fast::box_key_f64 applies it) box by box: seeded random rays
+    and boxes plus the adversarial corners — origins up to 1e7 from the scene with direction components down to 1e-17 (1 / d
+    just under the 1e18 switch to the exact test), boxes of clamped infinite shapes (+-1e7, bounding_box.rs:154-157), limits
+    that graze a box's entry time, f32-denormal direction components, flat boxes, rays starting on a box face.  Wherever the
+    production traversal uses the f32 test, it must keep every box the exact test keeps."""
+    import ctypes as C
+    rng = np.random.default_rng(20240611)
+    L = N.core_lib()
+    n = 1 << 20
+
+    def run(o, d, boxes, limit, all_t):
+        out = np.zeros(len(o), dtype=np.uint8)
+        o, d = np.ascontiguousarray(o, np.float64), np.ascontiguousarray(d, np.float64)
+        boxes, limit = np.ascontiguousarray(boxes, np.float32), np.ascontiguousarray(limit, np.float64)
+        pd = C.POINTER(C.c_double)
+        rc = L.rt_debug_box_tests(len(o), o.ctypes.data_as(pd), d.ctypes.data_as(pd), boxes.ctypes.data_as(C.POINTER(C.c_float)),
+                                  limit.ctypes.data_as(pd), all_t, out.ctypes.data_as(C.POINTER(C.c_uint8)))
+        assert rc == 0, L.rt_last_error().decode()
+        return out
+
+    def make(kind):
+        scale = {"near": 3., "far": 1e4, "huge": 1e7}[kind[0]]
+        o = rng.uniform(-scale, scale, (n, 3))
+        d = rng.normal(size=(n, 3))
+        d /= np.linalg.norm(d, axis=1, keepdims=True)
+        if kind[1] == "tiny":      # one or two components tiny: 1 / d up to just under 1e18 (the switch to the exact test)
+            mask = rng.random((n, 3)) < 0.4
+            d = np.where(mask, d * 10. ** rng.uniform(-17.9, -3., (n, 3)), d)
+        elif kind[1] == "denormal":  # components that are denormal (or zero) as f32
+            mask = rng.random((n, 3)) < 0.4
+            d = np.where(mask, np.sign(d) * 10. ** rng.uniform(-46., -37.5, (n, 3)), d)
+        c = rng.uniform(-scale, scale, (n, 3)) if kind[2] != "clamped" else np.zeros((n, 3))
+        half = 10. ** rng.uniform(-6., np.log10(scale), (n, 3))
+        if kind[2] == "flat":
+            half[np.arange(n), rng.integers(0, 3, n)] = 0.
+        if kind[2] == "clamped":   # an infinite shape's box: +-1e7 on two axes, thin on the third (a plane)
+            half[:] = 1e7
+            ax = rng.integers(0, 3, n)
+            half[np.arange(n), ax] = 10. ** rng.uniform(-9., 0., n)
+        lo, hi = (c - half).astype(np.float32), (c + half).astype(np.float32)
+        if kind[2] == "onface":    # the ray starts exactly on a face of the box
+            k = rng.integers(0, 3, n)
+            o[np.arange(n), k] = lo[np.arange(n), k].astype(np.float64)
+        boxes = np.concatenate([lo, hi], axis=1)
+        # limits: infinite, random, and grazing the exact entry time from both sides
+        with np.errstate(all="ignore"):
+            t0, t1 = (lo - o) / d, (hi - o) / d
+            entry = np.nanmax(np.minimum(t0, t1), axis=1)
+        limit = np.where(rng.random(n) < 0.3, np.inf, 10. ** rng.uniform(-3., 8., n))
+        graze = rng.random(n) < 0.4
+        limit = np.where(graze & np.isfinite(entry) & (entry > 0), entry * (1. + rng.choice([-1e-9, -1e-12, 0., 1e-12, 1e-9], n)), limit)
+        return o, d, boxes, np.abs(limit)
+
+    total_kept = 0
+    for kind in [("near", "plain", "any"), ("far", "plain", "any"), ("huge", "tiny", "any"), ("near", "tiny", "flat"), ("far", "denormal", "any"),
+                 ("huge", "plain", "clamped"), ("near", "tiny", "clamped"), ("near", "plain", "onface"), ("far", "tiny", "onface")]:
+        o, d, boxes, limit = make(kind)
+        for all_t in (0, 1):
+            out = run(o, d, boxes, limit, all_t)
+            f32_path = (out & 4) == 0
+            missed = f32_path & ((out & 2) != 0) & ((out & 1) == 0)
+            assert not missed.any(), (kind, all_t, int(missed.sum()), o[missed][:2], d[missed][:2], boxes[missed][:2], limit[missed][:2])
+            total_kept += int((f32_path & ((out & 2) != 0)).sum())
+            # (and it still culls: the test is not "keep everything")
+            assert (f32_path & ((out & 1) == 0)).sum() > 0 or kind[2] == "clamped"
+    assert total_kept > 100000
