@@ -113,6 +113,10 @@ extern "C" {
     /// One-shot render: uploads the scene, renders, downloads `width*height*3` f64 (row-major r,g,b).
     pub fn rt_render(scene: *const rt_scene_desc, camera: *const rt_camera, options: *const rt_options,
                      out_rgb: *mut f64, stats: *mut c_void /* rt_stats*, nullable */) -> i32;
+    /// The same with `Color::as_scaled_values` (color.rs:55-66) applied on the device: `width*height*3` bytes, what
+    /// `Image::as_u8_rgb` (image.rs:84-89) hands the PNG / video encoders.
+    pub fn rt_render_u8(scene: *const rt_scene_desc, camera: *const rt_camera, options: *const rt_options,
+                        out_rgb8: *mut u8, stats: *mut c_void) -> i32;
     // resident-scene API (animations, multi-GPU): see include/rtcore.h
     pub fn rt_scene_create(scene: *const rt_scene_desc, out: *mut *mut c_void) -> i32;
     pub fn rt_scene_destroy(scene: *mut c_void);
