@@ -175,6 +175,8 @@ struct DevScene {
   const double* light_intensity;
   uint32_t n_lights;
   uint32_t n_prims;
+  uint32_t has_walks;  // 0: no closest hit of this scene is followed by the container walk (prim_flags all clear), so the
+                       // refractive indices of every hit are (1.0, 1.0) and the streamed pipeline neither stores nor reads them
 };
 
 struct DevOptions {

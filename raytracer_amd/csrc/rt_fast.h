@@ -528,6 +528,9 @@ __device__ __forceinline__ bool trav_busy(const Trav& T) { return T.cur != RT_FR
 #ifndef RT_NODE_BREAK
 #define RT_NODE_BREAK 16
 #endif
+#ifndef RT_COUNT_PHASE
+#define RT_COUNT_PHASE 0  // statistics builds: what wave_steps / lane_steps count.  0: node steps and leaf visits (the documented
+#endif                    // meaning); dev builds: 1 node steps only, 2 triangle tests only, 3 analytic-primitive tests only
 #ifndef RT_TRI_PREFETCH
 #define RT_TRI_PREFETCH 1  // fetch the next triangle of a leaf's run while this one is tested (20 more live registers)
 #endif
@@ -564,7 +567,7 @@ __device__ __forceinline__ void trav_run(const DevScene& s, Trav& T, uint2* lds,
         if (act < (uint32_t)RT_NODE_BREAK && act < busy0) break;
       }
 #endif
-      if (STATS) count_step(cnt);
+      if (STATS && (RT_COUNT_PHASE == 0 || RT_COUNT_PHASE == 1)) count_step(cnt);
       // The whole node is fetched first (16-B loads, all in flight together), then tested: written out by hand because
       // the compiler otherwise fetches and waits box by box.
       const bool all_t = in_mode<MS>(T, M_CONTAINERS);
@@ -703,7 +706,7 @@ __device__ __forceinline__ void trav_run(const DevScene& s, Trav& T, uint2* lds,
     if ((leaf >> RT_FREF_KIND_SHIFT) == RT_FREF_INNER) continue;
 #endif
     // ---- leaf ----
-    if (STATS) count_step(cnt);
+    if (STATS && RT_COUNT_PHASE == 0) count_step(cnt);
     uint32_t kind = leaf >> RT_FREF_KIND_SHIFT;
     uint32_t count = (leaf >> RT_FREF_COUNT_SHIFT) & RT_FREF_COUNT_MASK, first = leaf & RT_FREF_INDEX_MASK;
     if (kind == RT_FREF_TRIS) {
@@ -728,6 +731,7 @@ __device__ __forceinline__ void trav_run(const DevScene& s, Trav& T, uint2* lds,
         pin_loaded(r0, r1, r2, r3, r4);
         const double tri[RT_TRI_STRIDE] = {r0.x, r0.y, r1.x, r1.y, r2.x, r2.y, r3.x, r3.y, r4.x, r4.y};
         double t, u, v;
+        if (STATS && RT_COUNT_PHASE == 2) count_step(cnt);
         if (STATS) cnt.tri_tests++;
         if (triangle_roots(tri, T.o, T.d, &t, u, v)) {
           const unsigned long long last = (unsigned long long)__double_as_longlong(tri[9]);
@@ -753,6 +757,7 @@ __device__ __forceinline__ void trav_run(const DevScene& s, Trav& T, uint2* lds,
     } else {  // RT_FREF_PRIMS
       for (uint32_t j = 0; j < count; j++) {
         // the whole 128-B entry in one go
+        if (STATS && RT_COUNT_PHASE == 3) count_step(cnt);
         const uint4* rp = reinterpret_cast<const uint4*>(s.leaf_rec + (first + j));
         uint4 h0 = rp[0];
         double2 m0 = reinterpret_cast<const double2*>(rp)[1], m1 = reinterpret_cast<const double2*>(rp)[2],

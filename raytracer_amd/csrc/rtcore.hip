@@ -1614,6 +1614,9 @@ struct TimedLaunch {  // records an event before and after one launch when the s
 #ifndef RT_SHADOW_SIDE_SAMPLES
 #define RT_SHADOW_SIDE_SAMPLES (64u << 20)
 #endif
+#ifndef RT_SHADOW_SIDE_LEVELS
+#define RT_SHADOW_SIDE_LEVELS 1u  // levels 0 .. this - 1: a shadow launch per level on the side stream; the rest: one launch at the end
+#endif
 #ifndef RT_CLOSEST_BIG_SAMPLES
 #define RT_CLOSEST_BIG_SAMPLES (64u << 20)  // (rt_stream.h, RT_CLOSEST_WAVES_NO_WALK; a 1080p ss 4 batch of 33 M samples is no faster with it)
 #endif
@@ -1639,6 +1642,10 @@ int run_stream_batch(const rt_scene* sc, const stream::Ws& w, const rt_camera& c
     return e ? std::strtoull(e, nullptr, 10) : (uint64_t)RT_SHADOW_SIDE_SAMPLES;
   }();
   const bool use_side = RT_SHADOW_ON_SIDE_STREAM && allow_side && dopt.max_depth > 0 && b.n_samples < side_below;
+  static const uint32_t side_levels = [] {
+    const char* e = std::getenv("RT_SHADOW_SIDE_LEVELS");
+    return e ? (uint32_t)std::strtoul(e, nullptr, 10) : (uint32_t)RT_SHADOW_SIDE_LEVELS;
+  }();
   hipStream_t side = use_side ? sc->side_stream : st;
   auto launch_shadow = [&](uint32_t first, uint32_t last, hipStream_t on) {
     if (STATS || sc->has_csg)
@@ -1688,17 +1695,18 @@ int run_stream_batch(const rt_scene* sc, const stream::Ws& w, const rt_camera& c
       TimedLaunch t(sc, st, TC_OTHER);
       hipLaunchKernelGGL(stream::close_level_kernel, dim3(1), dim3(64), 0, st, w, level);
     }
-    // the shadow rays of level 0 (most of them): on the side stream, beside the next levels' kernels
-    if (level == 0 && use_side) {
-      HIP_TRY(hipEventRecord(sc->level_event[0], st));
-      HIP_TRY(hipStreamWaitEvent(side, sc->level_event[0], 0));
+    // the shadow rays of the first levels: on the side stream, level by level, beside the next levels' kernels
+    if (use_side && level < side_levels) {
+      HIP_TRY(hipEventRecord(sc->level_event[level], st));
+      HIP_TRY(hipStreamWaitEvent(side, sc->level_event[level], 0));
       TimedLaunch t(sc, side, TC_TRACE_SHADOW);
-      launch_shadow(0u, 0u, side);
+      launch_shadow(level, level, side);
     }
   }
-  {  // the shadow rays of the other levels, in one launch
+  const uint32_t rest = use_side ? std::min<uint32_t>(side_levels, dopt.max_depth + 1u) : 0u;
+  if (rest <= dopt.max_depth) {  // the shadow rays of the other levels, in one launch
     TimedLaunch t(sc, st, TC_TRACE_SHADOW);
-    launch_shadow(use_side ? 1u : 0u, dopt.max_depth, st);
+    launch_shadow(rest, dopt.max_depth, st);
   }
   if (use_side) {  // the side stream's shadow kernel is what the fold over the lights waits for
     HIP_TRY(hipEventRecord(sc->side_event, side));
@@ -2490,6 +2498,7 @@ int rt_scene_create(const rt_scene_desc* d, rt_scene** out) try {
 #undef UPA
 #undef UPT
   sc->dev.n_lights = d->n_lights;
+  sc->dev.has_walks = sc->has_walks ? 1u : 0u;
   sc->dev.n_prims = (uint32_t)(d->n_prims + mesh_tris_total);
   sc->n_lights = d->n_lights;
   sc->has_csg = d->n_csgs > 0;
