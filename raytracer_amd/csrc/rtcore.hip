@@ -2585,6 +2585,9 @@ int rt_mesh_create(const rt_mesh_desc* d, rt_mesh** out) try {
   if (!d || d->n_tris == 0 || !d->shape || !d->p1 || !d->p2 || !d->p3 || !d->bbox || !d->material || d->n_palette == 0)
     return fail(RT_ERR_INVALID_ARGUMENT, "rt_mesh_desc: triangles, boxes and materials are required");
   if (d->n_tris > RT_MESH_MAX_TRIS) return fail(RT_ERR_UNSUPPORTED, "a mesh holds at most " + std::to_string(RT_MESH_MAX_TRIS) + " triangles");
+#ifdef RT_HOST_EMU
+  return fail(RT_ERR_UNSUPPORTED, "host emulation runs one lane at a time; the mesh kernels cooperate across a block");
+#endif
   const uint32_t n = d->n_tris;
   bool any_smooth = false;
   for (uint32_t i = 0; i < n; i++) {

@@ -46,6 +46,13 @@ template <class T> static inline T __hip_atomic_load(T* p, int, int) { return *p
 template <class T> static inline T atomicAdd(T* p, T v) { T o = *p; *p += v; return o; }
 static inline uint32_t atomicMax(uint32_t* p, uint32_t v) { uint32_t o = *p; if (v > o) *p = v; return o; }
 static inline uint32_t atomicOr(uint32_t* p, uint32_t v) { uint32_t o = *p; *p |= v; return o; }
+// (rt_mesh.h: its kernels cooperate across a block — barriers, LDS accumulators — which one lane at a time cannot emulate;
+// these only let the file compile, and rt_mesh_create refuses under RT_HOST_EMU)
+static inline void __syncthreads() {}
+template <class T, class V> static inline T atomicMin(T* p, V v) { T o = *p; if ((T)v < o) *p = (T)v; return o; }
+static inline unsigned long long atomicMax(unsigned long long* p, unsigned long long v) { unsigned long long o = *p; if (v > o) *p = v; return o; }
+template <class T> static inline T atomicCAS(T* p, T expect, T v) { T o = *p; if (o == expect) *p = v; return o; }
+template <class T> static inline T __shfl_up(T v, int, int) { return v; }
 
 typedef int hipError_t;
 typedef void* hipStream_t;
@@ -66,7 +73,7 @@ static inline hipError_t hipMemGetInfo(size_t* f, size_t* t) { *f = (size_t)6 <<
 static inline hipError_t hipGetLastError() { return hipSuccess; }
 static inline hipError_t hipGetDeviceCount(int* n) { *n = 1; return hipSuccess; }
 static inline hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
-static inline hipError_t hipMalloc(void** p, size_t n) { *p = std::malloc(n); return hipSuccess; }
+static inline hipError_t hipMalloc(void** p, size_t n) { *p = std::aligned_alloc(256, (n + 255) & ~(size_t)255); return hipSuccess; }  // (hipMalloc's alignment)
 #define __align__(n) alignas(n)
 typedef void (*hipHostFn_t)(void*);
 static inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }
@@ -81,6 +88,8 @@ enum { hipHostMallocDefault = 0, hipHostMallocPortable = 1, hipStreamNonBlocking
 static inline hipError_t hipHostMalloc(void** p, size_t n, unsigned = 0) { *p = std::malloc(n); return hipSuccess; }
 static inline hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) { *s = nullptr; return hipSuccess; }
 static inline hipError_t hipStreamDestroy(hipStream_t) { return hipSuccess; }
+enum hipStreamCaptureStatus { hipStreamCaptureStatusNone = 0, hipStreamCaptureStatusActive = 1 };
+static inline hipError_t hipStreamIsCapturing(hipStream_t, hipStreamCaptureStatus* s) { *s = hipStreamCaptureStatusNone; return hipSuccess; }
 static inline hipError_t hipHostFree(void* p) { std::free(p); return hipSuccess; }
 static inline hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { std::memcpy(d, s, n); return hipSuccess; }
 static inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t) { std::memcpy(d, s, n); return hipSuccess; }
