@@ -124,6 +124,9 @@ __device__ __forceinline__ uint32_t wave_take(uint32_t* counter, bool want) {
 #ifndef RT_XCD_GRAB
 #define RT_XCD_GRAB 1024u
 #endif
+#ifndef RT_XCD_GUIDE
+#define RT_XCD_GUIDE 1u  // guided grabs: the next grab is 2 / RT_XCD_GUIDE of what is left of the share per wavefront of the XCD
+#endif
 #ifndef RT_XCD_TURNS
 #define RT_XCD_TURNS 8u  // a wavefront's grab is sized so that it gets at least this many
 #endif
@@ -166,6 +169,22 @@ __device__ __forceinline__ uint32_t xcd_share(uint32_t n_items, uint32_t xx) {
   return share;
 }
 
+// A wavefront's private range is up to RT_XCD_GRAB = 1024 CONSECUTIVE positions, and consecutive rays cost alike: 1024 camera rays
+// are the sixteen sample planes of one 8x8 tile, all on a dragon or all in the sky (50x apart).  One wavefront working through an
+// expensive tile alone was the floor of a level-0 launch whatever the number of rays (1.1 ms of the 1.39 ms that an eighth of
+// the 4K frame takes, against 4.2 ms for the whole frame), and smaller grabs pay in same-address atomics instead (cap 256: the
+// whole frame 4.2 -> 6.6 ms).  So the positions of a (full) chunk are dealt out in groups of 64 with a stride of 64 groups: a
+// private range of 1024 positions is sixteen sample planes of sixteen DIFFERENT tiles four tiles apart, a fair sample of the
+// chunk, while each group of 64 — what a wavefront's lanes hold together — stays one sample plane of one tile.
+#ifndef RT_XCD_SPREAD
+#define RT_XCD_SPREAD 1
+#endif
+static_assert(RT_XCD_CHUNK == 65536u || !RT_XCD_SPREAD, "chunk_spread permutes the 1024 groups of a 64 Ki chunk");
+__device__ __forceinline__ uint32_t chunk_spread(uint32_t r) {
+  const uint32_t g = r >> 6;
+  return ((((g & 15u) << 6) | (g >> 4)) << 6) | (r & 63u);
+}
+
 // Every lane with `want` gets a distinct item id < n_items, or RT_NONE when nothing is left.
 __device__ __forceinline__ uint32_t xcd_take(uint32_t* counters, uint32_t n_items, XcdCursor& c, bool want) {
   uint32_t id = RT_NONE;
@@ -198,12 +217,13 @@ __device__ __forceinline__ uint32_t xcd_take(uint32_t* counters, uint32_t n_item
       // guided: the nearer the share's end, the smaller the next grab, so that no wavefront sits on a long private range
       // while the others have run dry
       uint32_t left = share - c.end;
-      c.grab = min(max((left / max(gridDim.x / 4u, 1u)) & ~63u, c.lanes), (uint32_t)RT_XCD_GRAB);
+      c.grab = min(max((left / max(gridDim.x * RT_XCD_GUIDE / 4u, 1u)) & ~63u, c.lanes), (uint32_t)RT_XCD_GRAB);
     }
     uint32_t avail = c.end - c.next, r = rank_in(m);
     if (w && r < avail) {
       uint32_t q = c.next + r;
-      id = ((q / RT_XCD_CHUNK) * 8u + xx) * RT_XCD_CHUNK + q % RT_XCD_CHUNK;
+      const uint32_t chunk0 = ((q / RT_XCD_CHUNK) * 8u + xx) * RT_XCD_CHUNK;
+      id = chunk0 + ((RT_XCD_SPREAD && n_items - chunk0 >= RT_XCD_CHUNK) ? chunk_spread(q % RT_XCD_CHUNK) : q % RT_XCD_CHUNK);
     }
     c.next += min(avail, (uint32_t)__builtin_popcountll(m));
   }
@@ -249,7 +269,7 @@ __device__ __forceinline__ bool xcd_range(uint32_t* counters, uint32_t n_items, 
     c.next = q;
     c.end = min(q + c.grab, share);
     const uint32_t left = share - c.end;
-    c.grab = min(max((left / max(gridDim.x / 4u, 1u)) & ~63u, c.lanes), (uint32_t)RT_XCD_GRAB);
+    c.grab = min(max((left / max(gridDim.x * RT_XCD_GUIDE / 4u, 1u)) & ~63u, c.lanes), (uint32_t)RT_XCD_GRAB);
     return true;
   }
   return false;
@@ -281,6 +301,8 @@ __device__ __forceinline__ uint32_t lit_take(const Ws& w, uint32_t* counters, ui
       uint32_t xx = 0;
       if (!xcd_range(counters, n_items, c, xx)) break;
       const uint32_t q = c.next, n_win = min(wave, min(c.end - q, RT_XCD_CHUNK - q % RT_XCD_CHUNK));
+      // (not chunk_spread: a wavefront's successive windows are neighbouring surface points facing the same light, and dealing
+      // them apart cost the 4K frame's shadow rays 12.7 -> 14.1 ms)
       win.id0 = ((q / RT_XCD_CHUNK) * 8u + xx) * RT_XCD_CHUNK + q % RT_XCD_CHUNK;
       c.next += n_win;
       bool lit = false;
