@@ -6,7 +6,7 @@ out=$PWD/gpurun_out/prof_$tag
 mkdir -p $out
 export TMPDIR=/tmp
 run() { name=$1; shift; timeout -s KILL 240 rocprofv3 "$@" --output-format csv -d $out/$name -o $name -- python3 tools/prof_driver.py dragons_4k_ss4_d5 2 > $out/$name.log 2>&1 || { echo "pass $name failed"; tail -5 $out/$name.log; exit 1; }; echo "pass $name ok"; }
-timeout -s KILL 400 rocprofv3 --kernel-trace --stats --output-format csv -d $out/bench -o bench -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline > $out/bench.log 2>&1 || { echo bench trace failed; tail -5 $out/bench.log; exit 1; }
+timeout -s KILL 400 rocprofv3 --kernel-trace --stats --output-format csv -d $out/bench -o bench -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-one-shot > $out/bench.log 2>&1 || { echo bench trace failed; tail -5 $out/bench.log; exit 1; }
 echo "pass bench ok"
 run sq1 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VMEM &&
 run sq2 --pmc SQ_INSTS_VALU SQ_THREAD_CYCLES_VALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_SMEM SQ_ACTIVE_INST_LDS &&
