@@ -46,7 +46,7 @@ namespace stream {
 // Node tables are struct-of-arrays: field f of node i at [f * cap_nodes + i], so that a wavefront working on consecutive
 // nodes reads and writes whole cache lines.
 enum { NF_OVER = 0, NF_EYE = 3, NF_NORMAL = 6, NF_N1 = 9, NF_N2 = 10, NF_REFL = 11, NF_REFR = 14, NF_COUNT = 17 };
-enum { NU_PRIM = 0, NU_PARENT = 1, NU_ROOT = 2, NU_COUNT = 3 };
+enum { NU_PRIM = 0, NU_PARENT = 1, NU_COUNT = 2 };
 #define RT_NODE_REFLECTED 0x80000000u  // NU_PRIM: a reflected ray was traced for this hit (integrator.rs:154-168)
 #define RT_NODE_REFRACTED 0x40000000u  // NU_PRIM: a refracted ray was traced (integrator.rs:170-197)
 #define RT_NODE_PRIM_MASK 0x3FFFFFFFu
@@ -753,6 +753,14 @@ __global__ __launch_bounds__(64, 2) void retrace_kernel(DevScene s, rt_camera ca
 // reflected / refracted rays of the next level (integrator.rs:154-197).
 // ---------------------------------------------------------------------------------------------
 // One hit -> its node record and its child rays' origin/direction (shared by both loop shapes below).
+// EXPERIMENT, off by default.  The eye vector of a level-0 node is minus the direction of its sample's camera ray
+// (IntersecComputations::new, intersection.rs:225): the combine kernel can compute it again from the sample id — the same
+// operations on the same operands, so the same bits — instead of the shade kernel storing and the combine kernel loading 24
+// bytes per node (33 M nodes on the 4K frame).  Measured: shade 3.20 -> 2.99 ms, combine 2.05 -> 2.36 ms: the combine kernel
+// (128 registers, 4 spilled, ~1000 instructions per node) pays more for ~150 more instructions than for 24 bytes.
+#ifndef RT_EYE_FROM_CAMERA
+#define RT_EYE_FROM_CAMERA 0
+#endif
 struct ShadeOut {
   bool want_reflect, want_refract;
   d3 child_o[2], child_d[2];
@@ -806,9 +814,11 @@ __device__ __forceinline__ void shade_hit(const DevScene& s, const rt_camera& ca
   nf[(NF_OVER + 0) * cap] = g.over.x;
   nf[(NF_OVER + 1) * cap] = g.over.y;
   nf[(NF_OVER + 2) * cap] = g.over.z;
-  nf[(NF_EYE + 0) * cap] = g.eye.x;
-  nf[(NF_EYE + 1) * cap] = g.eye.y;
-  nf[(NF_EYE + 2) * cap] = g.eye.z;
+  if (!RT_EYE_FROM_CAMERA || level != 0) {  // (level 0: combine_kernel has it from the sample's camera ray again)
+    nf[(NF_EYE + 0) * cap] = g.eye.x;
+    nf[(NF_EYE + 1) * cap] = g.eye.y;
+    nf[(NF_EYE + 2) * cap] = g.eye.z;
+  }
   nf[(NF_NORMAL + 0) * cap] = g.normal.x;
   nf[(NF_NORMAL + 1) * cap] = g.normal.y;
   nf[(NF_NORMAL + 2) * cap] = g.normal.z;
@@ -825,7 +835,6 @@ __device__ __forceinline__ void shade_hit(const DevScene& s, const rt_camera& ca
   uint32_t* nu = w.node_u + node;
   nu[NU_PRIM * cap] = prim | (out.want_reflect ? RT_NODE_REFLECTED : 0u) | (out.want_refract ? RT_NODE_REFRACTED : 0u);
   nu[NU_PARENT * cap] = parent;
-  nu[NU_ROOT * cap] = root;
 }
 
 // The rays of level + 1 of one wavefront: its reflected rays from queue slot `base_reflect` on, its refracted rays from
@@ -1181,7 +1190,8 @@ __global__ __launch_bounds__(64, (CSG && !STATS) ? RT_TRACE_WAVES_CSG : RT_TRACE
 #ifndef RT_COMBINE_WAVES
 #define RT_COMBINE_WAVES 4  // 128 registers, 4 spilled: 2.34 -> 2.10 ms on the 4K frame against 3 (138 registers, none spilled)
 #endif
-__global__ __launch_bounds__(256, RT_COMBINE_WAVES) void combine_kernel(DevScene s, DevOptions opt, Ws w, uint32_t level) {
+template <bool CAMERA>
+__global__ __launch_bounds__(256, RT_COMBINE_WAVES) void combine_kernel(DevScene s, rt_camera cam, DevOptions opt, Ws w, Batch b, uint32_t level) {
   const uint32_t begin = level == 0 ? 0u : w.ctrl->level_end[level - 1], end = w.ctrl->level_end[level];
   const size_t cap = w.cap_nodes;
   for (uint32_t node = begin + blockIdx.x * blockDim.x + threadIdx.x; node < end; node += gridDim.x * blockDim.x) {
@@ -1191,7 +1201,14 @@ __global__ __launch_bounds__(256, RT_COMBINE_WAVES) void combine_kernel(DevScene
     uint4 info = s.prim_info[pf & RT_NODE_PRIM_MASK];
     const double* mat = s.material + (size_t)info.y * RT_MAT_STRIDE;
     d3 over = mk3(nf[(NF_OVER + 0) * cap], nf[(NF_OVER + 1) * cap], nf[(NF_OVER + 2) * cap]);
-    d3 eye = mk3(nf[(NF_EYE + 0) * cap], nf[(NF_EYE + 1) * cap], nf[(NF_EYE + 2) * cap]);
+    d3 eye;
+    if (RT_EYE_FROM_CAMERA && level == 0) {
+      d3 o, d;
+      first_ray<CAMERA>(cam, opt, b, parent, o, d);  // (parent: the sample)
+      eye = neg3(d);
+    } else {
+      eye = mk3(nf[(NF_EYE + 0) * cap], nf[(NF_EYE + 1) * cap], nf[(NF_EYE + 2) * cap]);
+    }
     d3 normal = mk3(nf[(NF_NORMAL + 0) * cap], nf[(NF_NORMAL + 1) * cap], nf[(NF_NORMAL + 2) * cap]);
     double kr = mat[RT_MAT_REFLECTIVITY], kt = mat[RT_MAT_TRANSPARENCY];
     d3 reflected = mk3(0., 0., 0.), refracted = mk3(0., 0., 0.);

@@ -1714,7 +1714,7 @@ int run_stream_batch(const rt_scene* sc, const stream::Ws& w, const rt_camera& c
   }
   for (uint32_t level = dopt.max_depth + 1; level-- > 0;) {
     TimedLaunch t(sc, st, TC_COMBINE);
-    hipLaunchKernelGGL(stream::combine_kernel, dim3(wide_grid), dim3(256), 0, st, sc->dev, dopt, w, level);
+    hipLaunchKernelGGL((stream::combine_kernel<CAMERA>), dim3(wide_grid), dim3(256), 0, st, sc->dev, cam, dopt, w, b, level);
   }
   {
     TimedLaunch t(sc, st, TC_OTHER);
