@@ -513,41 +513,13 @@ __device__ __forceinline__ void flag_sample(const Ws& w, uint32_t root) {
 #endif
 // WALK = false: for scenes in which no hit is followed by the container walk (DevScene::prim_flags all clear: no transparent
 // material, or every refractive index 1.0): the kernel carries no code or registers for it.
-// EXPERIMENT, off by default (RT_RAY_FIFO = 1): a wavefront keeps up to 64 PREPARED rays in LDS.  Without it a lane whose ray
-// is finished waits until fewer than RT_REFILL_BELOW = 24 lanes are still traversing, because taking work and setting a ray up
-// (a camera ray: ~300 instructions; a shadow ray: a square root and three divisions) costs the wavefront the same whether 8
-// lanes or 60 take part: node steps run at 43-48 of 64 lanes, triangle tests at 20 (profiles/r03c_phase_simd_before_fifo.txt).
-// With it the set-up is done by ALL lanes at once, for rays nobody needs yet (the traversal state of the busy lanes sits in
-// their registers and is not touched), and an idle lane's refill is 7 LDS reads and trav_start: cheap enough to do as soon as
-// RT_FIFO_REFILL_BELOW lanes are left traversing.  Measured on the 4K frame (profiles/r03c_ray_fifo_experiment.txt): shadow
-// rays 12.75 -> 15.2 / 16.0 / 17.6 ms at 24 / 40 / 52, closest hits 9.9 -> 10.9 / 10.9 / 11.4 ms, and the lanes active per
-// traversal step went DOWN (0.68 -> 0.63, 0.75 -> 0.70 at 52): rays that start together stay in step — all at inner nodes, then
-// all at leaves —, and a lane that joins whenever it is free is in the node loop while its neighbours test triangles.  The
-// batch refill is what keeps the phases of a wavefront aligned; what it costs (lanes idle until the batch is due) is the
-// price of that.  4 KB more LDS per wavefront also costs the shadow kernel 3 of its 16 wavefronts per CU (2 ms of the above;
-// a 12-entry LDS stack wins them back: 16.0 -> 14.0 ms at 40).
-#ifdef RT_HOST_EMU
-#define RT_RAY_FIFO 0
-#endif
-#ifndef RT_RAY_FIFO
-#define RT_RAY_FIFO 0
-#endif
-#ifndef RT_FIFO_REFILL_BELOW
-#define RT_FIFO_REFILL_BELOW 52
-#endif
-struct RayFifo {     // (wave-uniform)
-  uint32_t n;        // prepared rays in slots [0, n)
-  bool dry;          // the launch has no more items for this wavefront
-};
-__device__ __forceinline__ void fifo_put3(double* f, uint32_t field, uint32_t slot, d3 v) {
-  f[(field + 0u) * 64u + slot] = v.x;
-  f[(field + 1u) * 64u + slot] = v.y;
-  f[(field + 2u) * 64u + slot] = v.z;
-}
-__device__ __forceinline__ d3 fifo_get3(const double* f, uint32_t field, uint32_t slot) {
-  return mk3(f[(field + 0u) * 64u + slot], f[(field + 1u) * 64u + slot], f[(field + 2u) * 64u + slot]);
-}
-
+// EXPERIMENT of round 3, removed again (it is commit 35943d7 of this repository; numbers in profiles/r03c_ray_fifo_experiment.txt
+// and DESIGN.md §5): a wavefront kept up to 64 PREPARED rays in LDS — set up by all lanes at once, for rays nobody needed yet —
+// so that an idle lane's refill was 7 LDS reads and trav_start, cheap enough to do as soon as 52 (40, 24) lanes were left
+// traversing instead of below RT_REFILL_BELOW = 24.  Shadow rays 12.75 -> 17.6 (16.0, 15.2) ms, closest hits 9.9 -> 11.4 ms, and
+// the lanes active per traversal step went DOWN (0.68 -> 0.63): rays that start together stay in step — all at inner nodes,
+// then all at leaves —, and a lane that joins whenever it is free is in the node loop while its neighbours test triangles.
+// The batch refill is what keeps the phases of a wavefront aligned; the lanes idle before it are the price of that.
 template <bool CAMERA, bool STATS, bool CSG, bool FIRST, bool WALK = true, int WAVES = RT_CLOSEST_WAVES>
 __global__ __launch_bounds__(64, WAVES) void trace_closest_kernel(DevScene s, rt_camera cam, DevOptions opt, Ws w, Batch b,
                                                                           uint32_t level, unsigned long long* stats,
@@ -572,67 +544,9 @@ __global__ __launch_bounds__(64, WAVES) void trace_closest_kernel(DevScene s, rt
   const uint32_t lanes = lanes_in_use(n_rays);
   bool exhausted = (threadIdx.x & 63u) >= lanes;
   XcdCursor cursor = xcd_cursor(n_rays, lanes);
-#if RT_RAY_FIFO
-  __shared__ double fifo_f[6 * 64];  // origin, direction
-  __shared__ uint32_t fifo_id[64];
-  RayFifo fifo = {0u, false};
-  const uint32_t lane = threadIdx.x & 63u;
-#endif
   for (;;) {
     // ---- idle lanes take the next rays of the level ----
     bool want = my == RT_NONE && !exhausted;
-#if RT_RAY_FIFO
-    for (unsigned long long wm = __builtin_amdgcn_ballot_w64(want); wm != 0ull; wm = __builtin_amdgcn_ballot_w64(want)) {
-      if (fifo.n == 0u) {
-        if (fifo.dry) {
-          if (want) exhausted = true;
-          want = false;
-          continue;
-        }
-        // every lane prepares one ray
-        const bool take = lane < lanes;
-        const uint32_t id = xcd_take(w.ctrl->fetch[level], n_rays, cursor, take);
-        if (__builtin_amdgcn_ballot_w64(take && id != RT_NONE) == 0ull) {
-          fifo.dry = true;
-          continue;
-        }
-        d3 o = mk3(0., 0., 0.), d = o;
-        bool ok = false;
-        if (take && id != RT_NONE) {
-          if (FIRST) {
-            ok = first_ray<CAMERA>(cam, opt, b, id, o, d);
-            if (!ok) store_hit(w, level, id, RT_NONE, 0., 0., 0., 0., 0.);
-          } else {
-            uint32_t parent, root;
-            load_ray(queue, id, o, d, parent, root);
-            ok = true;
-          }
-        }
-        const unsigned long long okm = __builtin_amdgcn_ballot_w64(ok);
-        if (ok) {
-          const uint32_t slot = rank_in(okm);
-          fifo_put3(fifo_f, 0u, slot, o);
-          fifo_put3(fifo_f, 3u, slot, d);
-          fifo_id[slot] = id;
-        }
-        fifo.n = (uint32_t)__builtin_popcountll(okm);
-        __builtin_amdgcn_wave_barrier();
-        continue;
-      }
-      // the k-th idle lane takes the k-th prepared ray from the top
-      const uint32_t k = rank_in(wm), n_pop = min(fifo.n, (uint32_t)__builtin_popcountll(wm));
-      if (want && k < n_pop) {
-        const uint32_t slot = fifo.n - 1u - k;
-        const d3 o = fifo_get3(fifo_f, 0u, slot), d = fifo_get3(fifo_f, 3u, slot);
-        my = fifo_id[slot];
-        if (STATS && FIRST) cnt.rays_primary++;
-        fast::trav_start(T, o, d, fast::M_CLOSEST, INFINITY);
-        want = false;
-      }
-      fifo.n -= n_pop;
-      __builtin_amdgcn_wave_barrier();
-    }
-#else
     if (__builtin_amdgcn_ballot_w64(want) != 0ull) {
       uint32_t id = xcd_take(w.ctrl->fetch[level], n_rays, cursor, want);
       if (want) {
@@ -657,17 +571,12 @@ __global__ __launch_bounds__(64, WAVES) void trace_closest_kernel(DevScene s, rt
         }
       }
     }
-#endif
     if (__builtin_amdgcn_ballot_w64(fast::trav_busy(T)) == 0ull) {
       if (__builtin_amdgcn_ballot_w64(!exhausted) == 0ull) break;
       continue;
     }
     // ---- traverse; once the queue is dry there is nothing to refill with, so run to completion ----
-#if RT_RAY_FIFO
-    uint32_t min_active = (fifo.dry && fifo.n == 0u) ? 0u : (uint32_t)RT_FIFO_REFILL_BELOW * lanes / 64u;
-#else
     uint32_t min_active = __builtin_amdgcn_ballot_w64(exhausted && (threadIdx.x & 63u) < lanes) != 0ull ? 0u : (uint32_t)RT_REFILL_BELOW * lanes / 64u;
-#endif
     fast::trav_run<STATS, WALK ? fast::MS_CLOSEST_CONTAINERS : fast::MS_CLOSEST, CSG>(s, T, lds, ovf, cnt, min_active, lds_top);
     // ---- lanes whose traversal is complete ----
     if (my != RT_NONE && !fast::trav_busy(T)) {
@@ -1055,88 +964,9 @@ __global__ __launch_bounds__(64, (CSG && !STATS) ? RT_TRACE_WAVES_CSG : RT_TRACE
   const uint32_t lanes = lanes_in_use(n_items);
   bool exhausted = (threadIdx.x & 63u) >= lanes;
   XcdCursor cursor = xcd_cursor(n_items, lanes);
-#if RT_RAY_FIFO
-  __shared__ double fifo_f[7 * 64];  // origin, direction, distance to the light
-  __shared__ uint32_t fifo_id[2 * 64];  // node, light
-  RayFifo fifo = {0u, false};
-  const uint32_t lane = threadIdx.x & 63u;
-#else
   LitWindow window = {0u, 0ull};
-#endif
   for (;;) {
     bool want = my == RT_NONE && !exhausted;
-#if RT_RAY_FIFO
-    for (unsigned long long wm = __builtin_amdgcn_ballot_w64(want); wm != 0ull; wm = __builtin_amdgcn_ballot_w64(want)) {
-      if (fifo.n == 0u) {
-        if (fifo.dry) {
-          if (want) exhausted = true;
-          want = false;
-          continue;
-        }
-        // the next (up to) 64 consecutive items of this wavefront's range: every lane looks at one, writes the zero of an
-        // unlit one (the light is behind the surface: no ray) and prepares the ray of a lit one
-        uint32_t xx = 0;
-        if (!xcd_range(w.ctrl->shadow_fetch[level], n_items, cursor, xx)) {
-          fifo.dry = true;
-          continue;
-        }
-        const uint32_t q = cursor.next, n_win = min(64u, min(cursor.end - q, RT_XCD_CHUNK - q % RT_XCD_CHUNK));
-        const uint32_t id0 = ((q / RT_XCD_CHUNK) * 8u + xx) * RT_XCD_CHUNK + q % RT_XCD_CHUNK;
-        cursor.next += n_win;
-        bool lit = false;
-        uint32_t node = 0, l = 0;
-        d3 over = mk3(0., 0., 0.), sdir = over;
-        double dist = 0.;
-        if (lane < n_win) {
-          const uint32_t item = id0 + lane;
-          l = item / n_nodes;
-          node = node0 + (item - l * n_nodes);
-          lit = all_lit || ((w.node_lit[node] >> l) & 1u) != 0u;  // (all_lit: more lights than node_lit has bits, lit_bits)
-          if (lit) {
-            const double* nf = w.node_f + node;
-            over = mk3(ld_stream(nf + (NF_OVER + 0) * cap), ld_stream(nf + (NF_OVER + 1) * cap), ld_stream(nf + (NF_OVER + 2) * cap));
-            const double* lp = s.light_pos + (size_t)l * 3;
-            d3 vv = sub3(mk3(lp[0], lp[1], lp[2]), over);  // get_point_shadow_dist_ray (integrator.rs:110-123)
-            dist = mag3(vv);
-            sdir = normalize3(vv);
-            if (all_lit) {
-              d3 normal = mk3(ld_stream(nf + (NF_NORMAL + 0) * cap), ld_stream(nf + (NF_NORMAL + 1) * cap), ld_stream(nf + (NF_NORMAL + 2) * cap));
-              lit = !(dot3(sdir, normal) < 0.);
-            }
-          }
-          if (!lit) {
-            st_stream(&w.shadow[(size_t)l * cap + node], 0.);
-            if (STATS) cnt.shadow_culled++;
-          }
-        }
-        const unsigned long long litm = __builtin_amdgcn_ballot_w64(lit);
-        if (lit) {
-          const uint32_t slot = rank_in(litm);
-          fifo_put3(fifo_f, 0u, slot, over);
-          fifo_put3(fifo_f, 3u, slot, sdir);
-          fifo_f[6u * 64u + slot] = dist;
-          fifo_id[slot] = node;
-          fifo_id[64u + slot] = l;
-        }
-        fifo.n = (uint32_t)__builtin_popcountll(litm);
-        __builtin_amdgcn_wave_barrier();
-        continue;
-      }
-      const uint32_t k = rank_in(wm), n_pop = min(fifo.n, (uint32_t)__builtin_popcountll(wm));
-      if (want && k < n_pop) {
-        const uint32_t slot = fifo.n - 1u - k;
-        const d3 over = fifo_get3(fifo_f, 0u, slot), sdir = fifo_get3(fifo_f, 3u, slot);
-        const double dist = fifo_f[6u * 64u + slot];
-        my = fifo_id[slot];
-        light = fifo_id[64u + slot];
-        if (STATS) cnt.rays_shadow++;
-        fast::trav_start(T, over, sdir, fast::M_SHADOW, dist);
-        want = false;
-      }
-      fifo.n -= n_pop;
-      __builtin_amdgcn_wave_barrier();
-    }
-#else
     if (__builtin_amdgcn_ballot_w64(want) != 0ull) {
       uint32_t id = lit_take<STATS>(w, w.ctrl->shadow_fetch[level], n_items, n_nodes, node0, all_lit, cursor, window, want, cnt);
       if (want) {
@@ -1163,16 +993,11 @@ __global__ __launch_bounds__(64, (CSG && !STATS) ? RT_TRACE_WAVES_CSG : RT_TRACE
         }
       }
     }
-#endif
     if (__builtin_amdgcn_ballot_w64(fast::trav_busy(T)) == 0ull) {
       if (__builtin_amdgcn_ballot_w64(!exhausted) == 0ull) break;
       continue;
     }
-#if RT_RAY_FIFO
-    uint32_t min_active = (fifo.dry && fifo.n == 0u) ? 0u : (uint32_t)RT_FIFO_REFILL_BELOW * lanes / 64u;
-#else
     uint32_t min_active = __builtin_amdgcn_ballot_w64(exhausted && (threadIdx.x & 63u) < lanes) != 0ull ? 0u : (uint32_t)RT_REFILL_BELOW * lanes / 64u;
-#endif
     fast::trav_run<STATS, fast::MS_SHADOW, CSG>(s, T, lds, ovf, cnt, min_active, lds_top);
     if (my != RT_NONE && !fast::trav_busy(T)) {
       st_stream(&w.shadow[(size_t)light * cap + my], T.a);
