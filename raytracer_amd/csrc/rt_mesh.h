@@ -99,8 +99,6 @@ struct MeshDev {
   uint32_t* blocksum;
   uint32_t* segtail;
   Ctrl* ctrl;
-  const struct MeshOut* out;  // this frame's MeshOut (device copy: the kernels that fill the scene's tables read it from here, so
-                              // that a frame's launches are the same from frame to frame and can be replayed as a graph)
 };
 
 // Where the build's results go: the scene's tables (rt_device.h) and this mesh's ranges in them.
@@ -214,9 +212,7 @@ __global__ __launch_bounds__(RT_MESH_BLOCK) void pose_kernel(MeshDev M, PoseArgs
 }
 
 // A frame's build starts: every triangle in the base order, one group holding them all.
-__global__ __launch_bounds__(RT_MESH_BLOCK) void begin_kernel(MeshDev M) {
-  const MeshOut& O = *M.out;
-  const uint32_t built = O.built;
+__global__ __launch_bounds__(RT_MESH_BLOCK) void begin_kernel(MeshDev M, MeshOut O, uint32_t built) {
   const uint32_t p = blockIdx.x * RT_MESH_BLOCK + threadIdx.x;
   if (p < M.n) {
     M.order[0][p] = p;
@@ -738,8 +734,7 @@ __device__ __forceinline__ uint32_t leaf_fref(const MeshDev& M, const MeshOut& O
 // One thread per group that split: its children's records for the reference-order walk (rt_reforder.h), and — groups at even
 // levels — the 4-wide node of the fast path: the group's two children, each replaced by ITS two children when it split too
 // (the boxes of the odd levels are not tested: rt_device.h).
-__global__ __launch_bounds__(RT_MESH_BLOCK) void fold_kernel(MeshDev M) {
-  const MeshOut O = *M.out;
+__global__ __launch_bounds__(RT_MESH_BLOCK) void fold_kernel(MeshDev M, MeshOut O) {
   const uint32_t m = blockIdx.x * RT_MESH_BLOCK + threadIdx.x;
   if (m == 0u || m >= M.n) return;
   const Bin b = M.bins[m];
@@ -791,8 +786,7 @@ __global__ __launch_bounds__(RT_MESH_BLOCK) void fold_kernel(MeshDev M) {
 
 // One thread per position: the triangle that ended up there, its primitive record, its visit rank, its child record; the
 // first position of a leaf group with more triangles than a run holds also writes the group's chain of wide nodes.
-__global__ __launch_bounds__(RT_MESH_BLOCK) void finalize_kernel(MeshDev M, uint32_t cur) {
-  const MeshOut O = *M.out;
+__global__ __launch_bounds__(RT_MESH_BLOCK) void finalize_kernel(MeshDev M, MeshOut O, uint32_t cur) {
   const uint32_t p = blockIdx.x * RT_MESH_BLOCK + threadIdx.x;
   if (p >= M.n) return;
   const uint32_t elem = M.order[cur][p], a = M.seg_of[cur][p];

@@ -520,13 +520,8 @@ struct rt_mesh {
   size_t block_bytes = 0;
   mesh::MeshDev dev{};
   hipStream_t stream = nullptr;
-  unsigned long long* h_box = nullptr;  // pinned: the posed group's box as keys, then a copy of the build's Ctrl, then this frame's MeshOut
+  unsigned long long* h_box = nullptr;  // pinned: the posed group's box as keys, then a copy of the build's Ctrl
   mesh::Ctrl* h_ctrl = nullptr;
-  mesh::MeshOut* h_out = nullptr;
-  // a frame's build — ~350 launches of 4-20 us kernels — recorded once and replayed as ONE graph launch while the number of
-  // levels to run stays the same (its arguments do not change from frame to frame: what does is read from dev.out)
-  hipGraphExec_t graph = nullptr;
-  uint32_t graph_levels = 0;
   bool posed = false;
   bool acc_clean = false;     // every accumulator is empty (true after a complete build)
   uint32_t last_levels = 0;   // levels of the previous frame's tree: how many to launch before looking
@@ -537,7 +532,6 @@ struct rt_mesh {
       (void)hipStreamSynchronize(stream);
       (void)hipStreamDestroy(stream);
     }
-    if (graph) (void)hipGraphExecDestroy(graph);
     if (block) (void)hipFree(block);
     if (h_box) (void)hipHostFree(h_box);
   }
@@ -1354,53 +1348,22 @@ std::string mesh_status_text(uint32_t status) {
   return t + "prepare this frame on the host instead";
 }
 
-// Enqueues one frame's build on the mesh's stream: this frame's MeshOut to the device, the levels [0, target), then the scene's
-// tables (written optimistically: when the tree turns out to be unfinished they are simply written again) and the control
-// block back to the host.  Everything here can be captured into a graph.
-int mesh_enqueue_build(rt_mesh* m, uint32_t target, uint32_t* cur_out) {
-  const mesh::MeshDev& M = m->dev;
-  hipStream_t st = m->stream;
-  const uint32_t grid = (m->n + RT_MESH_BLOCK - 1u) / RT_MESH_BLOCK;
-  HIP_TRY(hipMemcpyAsync((void*)M.out, m->h_out, sizeof(mesh::MeshOut), hipMemcpyHostToDevice, st));
-  HIP_TRY(hipMemsetAsync(M.dec, 0xFF, (size_t)m->n * sizeof(mesh::Dec), st));
-  HIP_TRY(hipMemsetAsync(M.bins, 0, (size_t)m->n * sizeof(mesh::Bin), st));
-  hipLaunchKernelGGL(mesh::begin_kernel, dim3(grid), dim3(RT_MESH_BLOCK), 0, st, M);
-  uint32_t cur = 0;
-  for (uint32_t level = 0; level < target; level++) {
-    hipLaunchKernelGGL(mesh::bin_kernel, dim3(grid), dim3(RT_MESH_BLOCK), 0, st, M, cur, level);
-    hipLaunchKernelGGL(mesh::choose_kernel, dim3((m->n + RT_MESH_CHOOSE_POS - 1u) / RT_MESH_CHOOSE_POS), dim3(RT_MESH_BLOCK), 0, st, M, cur, level);
-    hipLaunchKernelGGL(mesh::count_kernel, dim3(grid), dim3(RT_MESH_BLOCK), 0, st, M, cur, level);
-    hipLaunchKernelGGL(mesh::scatter_kernel, dim3(grid), dim3(RT_MESH_BLOCK), 0, st, M, cur, level);
-    cur ^= 1u;
-  }
-  hipLaunchKernelGGL(mesh::fold_kernel, dim3(grid), dim3(RT_MESH_BLOCK), 0, st, M);
-  hipLaunchKernelGGL(mesh::finalize_kernel, dim3(grid), dim3(RT_MESH_BLOCK), 0, st, M, cur);
-  HIP_TRY(hipMemcpyAsync(m->h_ctrl, M.ctrl, sizeof(mesh::Ctrl), hipMemcpyDeviceToHost, st));
-  *cur_out = cur;
-  return RT_OK;
-}
-
-#ifndef RT_MESH_GRAPH
-#define RT_MESH_GRAPH 1  // 0: every frame's build is enqueued launch by launch
-#endif
 // ObjectGroup::build_bvh (group.rs:144-167) for the posed mesh, then its part of the scene's tables.  Synchronous: returns
 // when the tables are complete.  levels_out: levels of the tree (a mesh that keeps its flat child list: 1);
 // max_leaf_out: the most triangles a group that does not split holds.
-// (in two halves, so that the builds of a scene's meshes run side by side on their streams: begin for all, then end for all)
-struct MeshBuild {
-  uint32_t cur = 0, level = 0;
-  bool built = false;
-};
-int mesh_build_begin(rt_mesh* m, const mesh::MeshOut& out, bool built, MeshBuild* state) {
+int mesh_build(rt_mesh* m, const mesh::MeshOut& out, bool built, uint32_t* levels_out, uint32_t* max_leaf_out) {
   const mesh::MeshDev& M = m->dev;
   hipStream_t st = m->stream;
-  *m->h_out = out;
-  m->h_out->built = built ? 1u : 0u;
+  const uint32_t grid = (m->n + RT_MESH_BLOCK - 1u) / RT_MESH_BLOCK;
+  HIP_TRY(hipMemsetAsync(M.dec, 0xFF, (size_t)m->n * sizeof(mesh::Dec), st));
+  HIP_TRY(hipMemsetAsync(M.bins, 0, (size_t)m->n * sizeof(mesh::Bin), st));
   if (!m->acc_clean) {
     const size_t items = (size_t)m->n * RT_MESH_ACC_PER_SEG;
     hipLaunchKernelGGL(mesh::acc_reset_kernel, dim3((unsigned)((items + RT_MESH_BLOCK - 1u) / RT_MESH_BLOCK)), dim3(RT_MESH_BLOCK), 0, st, M);
   }
   m->acc_clean = false;
+  hipLaunchKernelGGL(mesh::begin_kernel, dim3(grid), dim3(RT_MESH_BLOCK), 0, st, M, out, built ? 1u : 0u);
+  uint32_t cur = 0, level = 0;
   // levels to launch before looking: what the previous frame's tree needed and two more (the first frame: 2 log2 n)
   uint32_t target = 0;
   if (built) {
@@ -1409,69 +1372,26 @@ int mesh_build_begin(rt_mesh* m, const mesh::MeshOut& out, bool built, MeshBuild
       for (uint32_t v = m->n; v; v >>= 1) target += 2u;
     target = std::min<uint32_t>(std::max(target, 4u), RT_MESH_MAX_LEVELS);
   }
-  uint32_t cur = 0, level = target;
-#ifndef RT_HOST_EMU
-  if (RT_MESH_GRAPH && m->last_levels) {  // (not the first frame, whose guess of the depth is a guess)
-    // (a recorded graph is kept while it runs at least the levels wanted and at most six more — a level past the tree's last is
-    // four launches that find nothing to do —, so that a tree whose depth wobbles from frame to frame is not recorded anew)
-    if (m->graph && !built) target = m->graph_levels;
-    if (m->graph && built && m->graph_levels >= target && m->graph_levels <= target + 6u) target = m->graph_levels;
-    if (!m->graph || m->graph_levels != target) {
-      if (built) target = std::min<uint32_t>(target + 2u, RT_MESH_MAX_LEVELS);
-      if (m->graph) (void)hipGraphExecDestroy(m->graph);
-      m->graph = nullptr;
-      hipGraph_t recorded = nullptr;
-      HIP_TRY(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
-      int rc = mesh_enqueue_build(m, target, &cur);
-      hipError_t e = hipStreamEndCapture(st, &recorded);
-      if (rc) {
-        if (recorded) (void)hipGraphDestroy(recorded);
-        return rc;
-      }
-      HIP_TRY(e);
-      e = hipGraphInstantiate(&m->graph, recorded, nullptr, nullptr, 0);
-      (void)hipGraphDestroy(recorded);
-      HIP_TRY(e);
-      m->graph_levels = target;
-    }
-    cur = target & 1u;
-    level = target;
-    HIP_TRY(hipGraphLaunch(m->graph, st));
-  } else
-#endif
-  {
-    int rc = mesh_enqueue_build(m, target, &cur);
-    if (rc) return rc;
-  }
-  HIP_TRY(hipGetLastError());
-  state->cur = cur;
-  state->level = level;
-  state->built = built;
-  return RT_OK;
-}
-int mesh_build_end(rt_mesh* m, const MeshBuild& state, uint32_t* levels_out, uint32_t* max_leaf_out) {
-  const mesh::MeshDev& M = m->dev;
-  hipStream_t st = m->stream;
-  const uint32_t grid = (m->n + RT_MESH_BLOCK - 1u) / RT_MESH_BLOCK;
-  uint32_t cur = state.cur, level = state.level;
-  const bool built = state.built;
   for (;;) {
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(hipStreamSynchronize(st));
-    if (m->h_ctrl->status) return fail(RT_ERR_UNSUPPORTED, "device-side scene preparation: " + mesh_status_text(m->h_ctrl->status));
-    if (!(built && level < RT_MESH_MAX_LEVELS && m->h_ctrl->active[level] != 0u)) break;
-    // groups are still open: eight more levels, launch by launch, and the tables again
-    const uint32_t more = std::min<uint32_t>(level + 8u, RT_MESH_MAX_LEVELS);
-    for (; level < more; level++) {
+    for (; level < target; level++) {
       hipLaunchKernelGGL(mesh::bin_kernel, dim3(grid), dim3(RT_MESH_BLOCK), 0, st, M, cur, level);
       hipLaunchKernelGGL(mesh::choose_kernel, dim3((m->n + RT_MESH_CHOOSE_POS - 1u) / RT_MESH_CHOOSE_POS), dim3(RT_MESH_BLOCK), 0, st, M, cur, level);
       hipLaunchKernelGGL(mesh::count_kernel, dim3(grid), dim3(RT_MESH_BLOCK), 0, st, M, cur, level);
       hipLaunchKernelGGL(mesh::scatter_kernel, dim3(grid), dim3(RT_MESH_BLOCK), 0, st, M, cur, level);
       cur ^= 1u;
     }
-    hipLaunchKernelGGL(mesh::fold_kernel, dim3(grid), dim3(RT_MESH_BLOCK), 0, st, M);
-    hipLaunchKernelGGL(mesh::finalize_kernel, dim3(grid), dim3(RT_MESH_BLOCK), 0, st, M, cur);
+    // (the tables are written optimistically: when the tree turns out to be unfinished they are simply written again)
+    hipLaunchKernelGGL(mesh::fold_kernel, dim3(grid), dim3(RT_MESH_BLOCK), 0, st, M, out);
+    hipLaunchKernelGGL(mesh::finalize_kernel, dim3(grid), dim3(RT_MESH_BLOCK), 0, st, M, out, cur);
+    HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(m->h_ctrl, M.ctrl, sizeof(mesh::Ctrl), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    if (m->h_ctrl->status) return fail(RT_ERR_UNSUPPORTED, "device-side scene preparation: " + mesh_status_text(m->h_ctrl->status));
+    if (built && level < RT_MESH_MAX_LEVELS && m->h_ctrl->active[level] != 0u) {
+      target = std::min<uint32_t>(level + 8u, RT_MESH_MAX_LEVELS);
+      continue;
+    }
+    break;
   }
   m->acc_clean = true;
   m->cur = cur;
@@ -2612,8 +2532,7 @@ int rt_scene_create(const rt_scene_desc* d, rt_scene** out) try {
     MeshNeeds needs;
     needs.sub.assign(d->n_meshes, 0u);
     uint32_t fast_need = L.stack_need;
-    std::vector<MeshBuild> builds(d->n_meshes);
-    for (uint32_t k = 0; k < d->n_meshes; k++) {  // every mesh's build is enqueued on its own stream ...
+    for (uint32_t k = 0; k < d->n_meshes; k++) {
       rt_mesh* m = d->mesh[k];
       mesh::MeshOut o;
       o.nodes = const_cast<DevNode*>(sc->dev.nodes);
@@ -2635,26 +2554,9 @@ int rt_scene_create(const rt_scene_desc* d, rt_scene** out) try {
       o.root_entry = mesh_root_entry[k];
       o.built = d->mesh_built[k] ? 1u : 0u;
       std::memcpy(o.group_bb, d->mesh_bbox + (size_t)k * 6, sizeof(o.group_bb));
-      rc = mesh_build_begin(m, o, d->mesh_built[k] != 0, &builds[k]);
-      if (rc) {  // (nothing of an earlier mesh's build may still be writing the arena when the scene is destroyed)
-        for (uint32_t q = 0; q < k; q++) (void)hipStreamSynchronize(d->mesh[q]->stream);
-        return rc;
-      }
-    }
-    int first_rc = RT_OK;
-    std::string first_error;
-    for (uint32_t k = 0; k < d->n_meshes; k++) {  // ... and then waited for
-      rt_mesh* m = d->mesh[k];
       uint32_t levels = 0, max_leaf = 0;
-      rc = mesh_build_end(m, builds[k], &levels, &max_leaf);
-      if (rc) {
-        if (first_rc == RT_OK) {
-          first_rc = rc;
-          first_error = rt_last_error();
-        }
-        (void)hipStreamSynchronize(m->stream);
-        continue;
-      }
+      rc = mesh_build(m, o, d->mesh_built[k] != 0, &levels, &max_leaf);
+      if (rc) return rc;
       m->posed = false;  // (the scene has its own copy of everything: the mesh is free for the next frame's pose)
       // Stack entries the mesh's tree can add.  Reference-order walk: a binary tree of `levels` levels holds at most one
       // sibling per level.  Fast path: a 4-wide node per two levels, at most 3 entries held per node; a leaf group of more
@@ -2664,7 +2566,6 @@ int rt_scene_create(const rt_scene_desc* d, rt_scene** out) try {
       if (max_leaf > RT_FREF_LEAF_MAX) fast += 3u * ((max_leaf + 3u * RT_FREF_LEAF_MAX - 1u) / (3u * RT_FREF_LEAF_MAX));
       fast_need = std::max(fast_need, L.mesh_held[k] + fast);
     }
-    if (first_rc) return fail(first_rc, first_error);
     std::fill(memo.begin(), memo.end(), (int64_t)-1);
     const uint32_t need_all = stack_need(d, 0, memo, 0, &needs);
     if (need_all > RT_STACK_MAX)
@@ -2716,8 +2617,7 @@ int rt_mesh_create(const rt_mesh_desc* d, rt_mesh** out) try {
   const size_t o_ord0 = take((size_t)n * 4), o_ord1 = take((size_t)n * 4), o_seg0 = take((size_t)n * 4), o_seg1 = take((size_t)n * 4);
   const size_t o_segs = take((size_t)n * sizeof(mesh::Seg)), o_dec = take((size_t)n * sizeof(mesh::Dec));
   const size_t o_acc = take((size_t)n * RT_MESH_ACC_PER_SEG * sizeof(mesh::Acc)), o_bins = take((size_t)n * sizeof(mesh::Bin));
-  const size_t o_bsum = take((size_t)RT_MESH_MAX_BLOCKS * 4), o_tail = take((size_t)n * 4), o_ctrl = take(sizeof(mesh::Ctrl)),
-               o_out = take(sizeof(mesh::MeshOut));
+  const size_t o_bsum = take((size_t)RT_MESH_MAX_BLOCKS * 4), o_tail = take((size_t)n * 4), o_ctrl = take(sizeof(mesh::Ctrl));
   m->block_bytes = off;
   if (hipMalloc(&m->block, m->block_bytes) != hipSuccess) {
     (void)hipGetLastError();
@@ -2769,15 +2669,12 @@ int rt_mesh_create(const rt_mesh_desc* d, rt_mesh** out) try {
   M.blocksum = (uint32_t*)(b + o_bsum);
   M.segtail = (uint32_t*)(b + o_tail);
   M.ctrl = (mesh::Ctrl*)(b + o_ctrl);
-  M.out = (const mesh::MeshOut*)(b + o_out);
   HIP_TRY(hipMemset(M.ctrl, 0, sizeof(mesh::Ctrl)));
   HIP_TRY(hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking));
   void* pinned = nullptr;
-  const size_t pinned_ctrl = (64 + sizeof(mesh::Ctrl) + 63) & ~(size_t)63;
-  HIP_TRY(hipHostMalloc(&pinned, pinned_ctrl + sizeof(mesh::MeshOut), hipHostMallocPortable));
+  HIP_TRY(hipHostMalloc(&pinned, 64 + sizeof(mesh::Ctrl), hipHostMallocPortable));
   m->h_box = (unsigned long long*)pinned;
   m->h_ctrl = (mesh::Ctrl*)((char*)pinned + 64);
-  m->h_out = (mesh::MeshOut*)((char*)pinned + pinned_ctrl);
   *out = owner.release();
   return RT_OK;
 } RT_NO_UNWIND

@@ -88,8 +88,6 @@ enum { hipHostMallocDefault = 0, hipHostMallocPortable = 1, hipStreamNonBlocking
 static inline hipError_t hipHostMalloc(void** p, size_t n, unsigned = 0) { *p = std::malloc(n); return hipSuccess; }
 static inline hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) { *s = nullptr; return hipSuccess; }
 static inline hipError_t hipStreamDestroy(hipStream_t) { return hipSuccess; }
-typedef void* hipGraphExec_t;
-static inline hipError_t hipGraphExecDestroy(hipGraphExec_t) { return hipSuccess; }
 enum hipStreamCaptureStatus { hipStreamCaptureStatusNone = 0, hipStreamCaptureStatusActive = 1 };
 static inline hipError_t hipStreamIsCapturing(hipStream_t, hipStreamCaptureStatus* s) { *s = hipStreamCaptureStatusNone; return hipSuccess; }
 static inline hipError_t hipHostFree(void* p) { std::free(p); return hipSuccess; }
