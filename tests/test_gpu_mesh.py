@@ -232,3 +232,28 @@ def test_unbuilt_and_tiny_meshes():
     assert float(np.abs(d.cpu().numpy() - want).max()) < 1e-9
     assert (check_wide_nodes(sd) == 1).all()
     sd.close()
+
+
+def test_builds_for_two_live_scenes():
+    """Two device scenes built from ONE mesh are alive at any time (an animation that prepares a frame ahead), so consecutive
+    frames' tables lie at different addresses and the mesh is posed again while the previous frame's scene still renders
+    from its own copy: every frame's triangles and pixels are the host-prepared scene's."""
+    kw = dict(width=96, height=72, supersampling_level=1, depth=3)
+    host = load("animations/general/rotating-dragon.yml", False, **kw)
+    dev = load("animations/general/rotating-dragon.yml", True, **kw)
+    alive = []
+    for i in range(7):
+        t = 0.13 * i
+        sd = R.DeviceScene(dev.builder.flatten_frame(t))
+        alive.append(sd)
+        sh = R.DeviceScene(host.builder.flatten_frame(t))
+        th, td = table(sh, TRI_ISECT, np.uint64).reshape(-1, 10), table(sd, TRI_ISECT, np.uint64).reshape(-1, 10)
+        assert th.shape == td.shape and np.array_equal(th[:, :9], td[:, :9]), f"frame {i}: triangles differ"
+        assert np.array_equal(table(sh, TRI_NORM, np.uint64), table(sd, TRI_NORM, np.uint64)), f"frame {i}"
+        assert (check_wide_nodes(sd) == 1).all()
+        assert np.array_equal(render(sh, host), render(sd, dev)), f"frame {i}: pixels differ"
+        sh.close()
+        if len(alive) > 2:
+            alive.pop(0).close()
+    for s in alive:
+        s.close()
