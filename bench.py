@@ -247,8 +247,27 @@ def main():
         for _ in range(2):
             torch.cuda.synchronize()
             t1 = time.perf_counter()
-            R.render_u8(flat, cam, opt)
+            img_u8, _ = R.render_u8(flat, cam, opt)
             one_shot_u8_ms = (time.perf_counter() - t1) * 1e3
+
+    one_shot_mesh_u8_ms = None
+    mesh_u8_same = None
+    if world == 1 and not args.no_one_shot:
+        # the same again with the scene's OBJ models handed over as device-resident meshes (rt_mesh_create once, outside the
+        # timed calls: what a host that renders more than one frame of a model does): the models' part of the scene's tree is
+        # then built on the device by rt_scene_create instead of being laid out on the host
+        rs_m = Y.load_scene(os.path.join(ROOT, path), width=w, height=h, depth=depth, supersampling_level=ss)
+        if rs_m.builder.extract_meshes(64) > 0:
+            import numpy as np
+            for _ in range(3):
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                flat_m = rs_m.builder.flatten()  # (poses the meshes: rt_mesh_pose)
+                img_m, _ = R.render_u8(flat_m, cam, opt)
+                one_shot_mesh_u8_ms = (time.perf_counter() - t1) * 1e3
+            mesh_u8_same = bool(np.array_equal(img_m, img_u8))
+            del flat_m
+        del rs_m
 
     # What 8 GPUs will cost, measured on this one (no scaling number is claimed: the driver measures that when it has a node):
     # each of the 8 cyclic parts of the frame rendered alone, as rank p of 8 would (rt_render_tiles_device), then the
@@ -353,6 +372,7 @@ def main():
                        "shadow_rays_not_traced_light_behind_surface": tot["rays_shadow_culled"],
                        "pipeline": "single kernel" if opt.pipeline else "streamed", "host_scene_prep_s": round(t_prep, 2),
                        "one_shot_ms": one_shot_ms, "one_shot_u8_ms": one_shot_u8_ms,
+                       "one_shot_mesh_u8_ms": one_shot_mesh_u8_ms, "one_shot_mesh_u8_equals_one_shot_u8": mesh_u8_same,
                        "part_of_8_ms": None if parts8 is None else {"max": parts8["ms_part_max"], "mean": parts8["ms_part_mean"]},
                        "predicted_8gpu_ms": None if parts8 is None else parts8["predicted_8gpu_ms"],
                        "eight_gpu_prediction": parts8},
