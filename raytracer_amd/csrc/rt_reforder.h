@@ -96,10 +96,11 @@ __device__ __forceinline__ void coll_add_roots(const DevScene& s, Coll& c, uint3
   }
 }
 
-template <int MODE, bool STATS>
+// BIG (a scene with rt_scene::general_csg): the general evaluation and its longer list (rt_shapes.h).
+template <int MODE, bool STATS, bool BIG = false>
 __device__ __forceinline__ void csg_intersect(const DevScene& s, uint32_t csg_root, d3 o, d3 d, Coll& c, Counters& cnt) {
-  CsgHit list[RT_CSG_LIST_MAX];
-  int n = csg_survivors<STATS>(s, csg_root, o, d, list, cnt);
+  CsgHit list[BIG ? RT_CSG_BIG_LIST : RT_CSG_LIST_MAX];
+  int n = BIG ? csg_survivors_general<STATS>(s, csg_root, o, d, list, cnt) : csg_survivors<STATS>(s, csg_root, o, d, list, cnt);
   // survivors -> outer collector, ascending t: collector.push(i) (csg.rs:119-121)
   if (MODE == MODE_CLOSEST) {
     int took = -1;
@@ -158,7 +159,7 @@ __device__ __forceinline__ void csg_intersect(const DevScene& s, uint32_t csg_ro
 // when t_enter >= hit_time, and a hit_time such a primitive sets is > bound).  The groups entered up to `bound` are
 // therefore visited, skipped and intersected exactly as in the unbounded walk, and the hit is the same; what is saved is
 // the rest of the scene behind it, which the reference walks in tree order, not front to back.
-template <int MODE, bool STATS>
+template <int MODE, bool STATS, bool BIG = false>
 __device__ __forceinline__ void traverse(const DevScene& s, d3 o, d3 d, Coll& c, Counters& cnt, double bound = INFINITY) {
   uint32_t stk_begin[RT_STACK_MAX];
   uint32_t stk_count[RT_STACK_MAX];
@@ -207,7 +208,7 @@ __device__ __forceinline__ void traverse(const DevScene& s, d3 o, d3 d, Coll& c,
         int n = prim_roots<STATS>(s, info, o, d, ts, u, v, cnt);
         if (n) coll_add_roots<MODE>(s, c, idx, info.y, n, ts, u, v);
       } else {
-        csg_intersect<MODE, STATS>(s, idx, o, d, c, cnt);
+        csg_intersect<MODE, STATS, BIG>(s, idx, o, d, c, cnt);
       }
     }
     if (MODE == MODE_SHADOW && c.intensity >= 1.) return;  // min(intensity, 1) is already 1 (intersection.rs:124-126)
@@ -230,7 +231,7 @@ struct Frame {
 };
 enum { ST_ENTER = 0, ST_AFTER_REFLECT = 1, ST_AFTER_REFRACT = 2 };
 
-template <bool STATS>
+template <bool STATS, bool BIG = false>
 __device__ d3 trace(const DevScene& s, const DevOptions& opt, d3 ro, d3 rd, Counters& cnt) {
   Frame frames[RT_FRAMES];
   int depth = 0;
@@ -248,7 +249,7 @@ __device__ d3 trace(const DevScene& s, const DevOptions& opt, d3 ro, d3 rd, Coun
     if (state == ST_ENTER) {
       Coll c;
       coll_init_closest(c);
-      traverse<MODE_CLOSEST, STATS>(s, o, d, c, cnt);
+      traverse<MODE_CLOSEST, STATS, BIG>(s, o, d, c, cnt);
 #ifdef RT_EMU_TRACE
       printf("ref   depth %d hit prim %u t %.17g o %.17g %.17g %.17g d %.17g %.17g %.17g | pa %u ta %.17g pb %u tb %.17g odd %d\n", depth, c.hit_prim, c.limit, o.x, o.y, o.z, d.x, d.y, d.z, c.pa, c.ta, c.pb, c.tb, (int)c.hit_neg_odd);
 #endif
@@ -355,7 +356,7 @@ __device__ d3 trace(const DevScene& s, const DevOptions& opt, d3 ro, d3 rd, Coun
         Coll sc;
         coll_init_shadow(sc, dist);
         if (STATS) cnt.rays_shadow++;
-        traverse<MODE_SHADOW, STATS>(s, g.over, sdir, sc, cnt);
+        traverse<MODE_SHADOW, STATS, BIG>(s, g.over, sdir, sc, cnt);
         double shadow = fmin(sc.intensity, 1.);
         if (!opt.shadow_intensity) shadow = approx_eq(shadow, 0.) ? 0. : 1.;
         d3 surface = lighting(s, l, info, mat, g.over, g.eye, g.normal, shadow);

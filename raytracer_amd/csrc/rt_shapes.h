@@ -297,6 +297,181 @@ __device__ __forceinline__ void csg_add_group(const DevScene& s, uint32_t entry,
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// The GENERAL evaluation (rt_scene::general_csg, reference-order kernels only): what the bounded one above refuses — more than
+// RT_CSG_LIST_MAX intersections per outermost object, nesting beyond RT_CSG_NEST_MAX, a CSG object inside a group that is
+// itself a CSG operand (csg.rs:113-115 + group.rs:171-201 + csg.rs again) — with the reference's recursion
+//   CsgObject::intersect -> Object::intersect(left / right, temp) -> { primitive | ObjectGroup::intersect_iter | CsgObject::intersect }
+// as ONE explicit frame stack: a CSG frame owns a temporary collector (its part of the hit list, from `start`, and its
+// closest positive t), a GROUP frame is a suspended intersect_iter (its pending sub-groups in a pool shared by the nested
+// group frames, its cursor in the child list being walked) feeding the collector of the nearest CSG frame below it.
+// Bounds, all checked by rt_scene_create except the list (a run-time flag -> RT_ERR_OVERFLOW): RT_CSG_BIG_LIST intersections
+// alive at once, RT_CSG_GEN_FRAMES frames, RT_CSG_GROUP_NEST nested group operands of RT_CSG_GROUP_STACK pending sub-groups.
+// ---------------------------------------------------------------------------------------------
+#define RT_CSG_BIG_LIST 256
+#define RT_CSG_GEN_FRAMES 16
+#define RT_CSG_GROUP_NEST 4
+#define RT_CSG_GEN_NEST_MAX 12  // CSG objects nested at most this deep (frames = CSG frames + group frames)
+template <bool STATS>
+__device__ __forceinline__ void csg_big_add_prim(const DevScene& s, uint32_t idx, d3 o, d3 d, CsgHit* list, int& n, double& hit_time,
+                                                 Counters& cnt) {
+  double ts[4], u, v;
+  int k = prim_roots<STATS>(s, s.prim_info[idx], o, d, ts, u, v, cnt);
+  for (int i = 0; i < k; i++) {
+    if (sign_positive(ts[i]) && ts[i] < hit_time) hit_time = ts[i];
+    if (n < RT_CSG_BIG_LIST) {
+      list[n].t = ts[i];
+      list[n].u = u;
+      list[n].v = v;
+      list[n].prim = idx;
+      n++;
+    } else {
+      cnt.overflow = 1;
+    }
+  }
+}
+template <bool STATS>
+__device__ int csg_survivors_general(const DevScene& s, uint32_t csg_root, d3 o, d3 d, CsgHit* list, Counters& cnt) {
+  struct GFrame {
+    uint32_t id;        // CSG frame: the object
+    uint32_t begin;     // GROUP frame: the child list being walked (DevEntry index) ...
+    uint32_t left;      // ... and how many of its children are still to visit (in reverse: the next is begin + left - 1)
+    int start;          // CSG frame: where its collector starts in the list
+    int owner;          // the CSG frame whose collector this frame's intersections go to (-1: the caller's, the outermost frame)
+    int gs_base;        // GROUP frame: its part of the pool of pending sub-groups starts here
+    uint8_t group, stage;
+    double hit;         // CSG frame: hit_time() of its temporary collector
+  };
+  GFrame fr[RT_CSG_GEN_FRAMES];
+  uint32_t gs_begin[RT_CSG_GROUP_NEST * RT_CSG_GROUP_STACK], gs_count[RT_CSG_GROUP_NEST * RT_CSG_GROUP_STACK];
+  double gs_t[RT_CSG_GROUP_NEST * RT_CSG_GROUP_STACK];
+  const d3 dinv = mk3(1. / d.x, 1. / d.y, 1. / d.z);  // Ray::new (ray.rs:27-34)
+  int n = 0, fp = 0, gsp = 0;
+  fr[0].id = csg_root;
+  fr[0].group = 0;
+  fr[0].stage = 0;
+  fr[0].start = 0;
+  fr[0].owner = -1;
+  fr[0].hit = INFINITY;
+  // Object::intersect(ref, collector of CSG frame `owner`) (object.rs:193-202): a primitive at once, anything else as a new frame
+  auto enter = [&](uint32_t ref, int owner) {
+    const uint32_t kind = ref >> RT_REF_KIND_SHIFT, idx = ref & RT_REF_INDEX_MASK;
+    if (kind == RT_REF_PRIM) {
+      csg_big_add_prim<STATS>(s, idx, o, d, list, n, fr[owner].hit, cnt);
+      return;
+    }
+    if (fp + 1 >= RT_CSG_GEN_FRAMES) {  // (cannot happen: rt_scene_create bounds the nesting)
+      cnt.overflow = 1;
+      return;
+    }
+    GFrame& g = fr[fp + 1];
+    g.owner = owner;
+    if (kind == RT_REF_CSG) {
+      g.id = idx;
+      g.group = 0;
+      g.stage = 0;
+      g.start = n;
+      g.hit = INFINITY;
+      fp++;
+      return;
+    }
+    // a group operand (idx: its DevEntry): ObjectGroup::intersect_iter starts with the group's own box (group.rs:172-175)
+    const DevEntry* root = s.entries + idx;
+    double bb[6], t;
+    for (int k = 0; k < 6; k++) bb[k] = root->bb[k];
+    if (STATS) cnt.node_visits++;
+    if (!bbox_time(bb, o, dinv, t)) return;
+    if (gsp + 1 > RT_CSG_GROUP_NEST * RT_CSG_GROUP_STACK) {
+      cnt.overflow = 1;
+      return;
+    }
+    g.group = 1;
+    g.gs_base = gsp;
+    g.left = 0;
+    g.begin = 0;
+    gs_begin[gsp] = root->begin;
+    gs_count[gsp] = root->count;
+    gs_t[gsp] = t;
+    gsp++;
+    fp++;
+  };
+  while (fp >= 0) {
+    GFrame& F = fr[fp];
+    if (F.group) {
+      if (F.left == 0) {  // the next pending sub-group (group.rs:176-183)
+        if (gsp == F.gs_base) {
+          fp--;
+          continue;
+        }
+        gsp--;
+        if (gs_t[gsp] >= fr[F.owner].hit) continue;
+        F.begin = gs_begin[gsp];
+        F.left = gs_count[gsp];
+        continue;
+      }
+      F.left--;  // children.iter().rev() (group.rs:185)
+      const DevEntry* e = s.entries + (size_t)(F.begin + F.left);
+      const uint32_t ref = e->ref, kind = ref >> RT_REF_KIND_SHIFT;
+      if (kind == RT_REF_NODE) {
+        double bb[6], t;
+        for (int k = 0; k < 6; k++) bb[k] = e->bb[k];
+        if (STATS) cnt.node_visits++;
+        if (bbox_time(bb, o, dinv, t)) {
+          if (gsp < RT_CSG_GROUP_NEST * RT_CSG_GROUP_STACK) {
+            gs_begin[gsp] = e->begin;
+            gs_count[gsp] = e->count;
+            gs_t[gsp] = t;
+            gsp++;
+          } else {
+            cnt.overflow = 1;
+          }
+        }
+      } else {
+        enter(ref, F.owner);  // (a CSG child suspends this walk: F.left is its cursor)
+      }
+      continue;
+    }
+    if (F.stage < 2) {
+      const uint32_t ref = F.stage == 0 ? s.csg_left[F.id] : s.csg_right[F.id];
+      F.stage++;
+      enter(ref, fp);
+      continue;
+    }
+    // both operands collected: collect_sorted (intersection.rs:110-114; a stable insertion sort) and filter_intersections
+    // (csg.rs:87-111)
+    const int start = F.start;
+    for (int i = start + 1; i < n; i++) {
+      CsgHit h = list[i];
+      int j = i - 1;
+      while (j >= start && list[j].t > h.t) {
+        list[j + 1] = list[j];
+        j--;
+      }
+      list[j + 1] = h;
+    }
+    bool inside_left = false, inside_right = false;
+    const uint32_t op = s.csg_op[F.id], depth = s.csg_depth[F.id];
+    int w = start;
+    for (int i = start; i < n; i++) {
+      const bool hit_left = (s.prim_csg_left[list[i].prim] >> depth) & 1u;  // self.left.includes(i.object())
+      if (hit_left) inside_left = !inside_left;
+      else inside_right = !inside_right;
+      bool allowed;
+      if (op == RT_CSG_UNION) allowed = hit_left ? !inside_right : !inside_left;
+      else if (op == RT_CSG_INTERSECTION) allowed = hit_left ? inside_right : inside_left;
+      else allowed = hit_left ? !inside_right : inside_left;
+      if (allowed) list[w++] = list[i];
+    }
+    n = w;
+    const int owner = F.owner;
+    fp--;
+    if (owner >= 0)  // the survivors are push()ed to the collector this object was intersected into (csg.rs:119-121)
+      for (int i = start; i < n; i++)
+        if (sign_positive(list[i].t) && list[i].t < fr[owner].hit) fr[owner].hit = list[i].t;
+  }
+  return n;
+}
+
 // Fills list[0..n) with the surviving intersections of the outermost CSG object `csg_root`, ascending t.
 template <bool STATS>
 __device__ __forceinline__ int csg_survivors(const DevScene& s, uint32_t csg_root, d3 o, d3 d, CsgHit* list, Counters& cnt) {

@@ -98,7 +98,8 @@ __device__ __forceinline__ uint32_t blocked_order(uint32_t j, uint32_t gx, uint3
 // Renderer::color_at_pixel (renderer.rs:50-66) for one 8x8 tile per wavefront, the whole recursion in one kernel.
 // REFORDER = false: the single-kernel core (rt_fast.h; rt_options.pipeline = 1, and the fallback of the streamed
 // pipeline).  REFORDER = true: reference visiting order (rt_reforder.h).
-template <bool STATS, bool REFORDER>
+// BIGCSG (with REFORDER): the general CSG evaluation (rt_shapes.h csg_survivors_general) for scenes the bounded one refuses.
+template <bool STATS, bool REFORDER, bool BIGCSG = false>
 __global__ __launch_bounds__(64, REFORDER ? 2 : RT_WAVES_PER_EU) void render_tiles_kernel(DevScene s, rt_camera cam, DevOptions opt, uint32_t part,
                                                                             uint32_t n_parts, uint32_t tiles_x, uint32_t n_owned,
                                                                             int packed, double* __restrict__ out,
@@ -125,7 +126,7 @@ __global__ __launch_bounds__(64, REFORDER ? 2 : RT_WAVES_PER_EU) void render_til
           d3 o, d;
           camera_ray(cam, x + opt.offsets[i], y + opt.offsets[j], o, d);
           if (STATS) cnt.rays_primary++;
-          color = add3(color, reforder::trace<STATS>(s, opt, o, d, cnt));
+          color = add3(color, reforder::trace<STATS, BIGCSG>(s, opt, o, d, cnt));
         }
     }
   } else {
@@ -193,7 +194,7 @@ __global__ __launch_bounds__(256) void quantize_kernel(const double* __restrict_
 }
 
 // Integrator::color_at for arbitrary rays (one lane per ray)
-template <bool REFORDER>
+template <bool REFORDER, bool BIGCSG = false>
 __global__ __launch_bounds__(64, REFORDER ? 2 : RT_WAVES_PER_EU) void trace_rays_kernel(DevScene s, DevOptions opt, uint32_t n,
                                                                           const double* __restrict__ origin,
                                                                           const double* __restrict__ dir, double* __restrict__ out,
@@ -208,7 +209,7 @@ __global__ __launch_bounds__(64, REFORDER ? 2 : RT_WAVES_PER_EU) void trace_rays
     d = mk3(dir[3 * i], dir[3 * i + 1], dir[3 * i + 2]);
   }
   if (REFORDER) {
-    if (valid) c = reforder::trace<false>(s, opt, o, d, cnt);
+    if (valid) c = reforder::trace<false, BIGCSG>(s, opt, o, d, cnt);
   } else {
     fast::OneRay rays;
     rays.o = o;
@@ -562,6 +563,10 @@ struct rt_scene {
   size_t bytes = 0;
   uint32_t stack_need = 0;
   uint32_t n_lights = 0;
+  bool general_csg = false;  // a CSG object of the scene is beyond what the production kernels evaluate (more than RT_CSG_LIST_MAX
+                             // intersections in the worst case, nesting beyond RT_CSG_NEST_MAX, a CSG object inside a group that
+                             // is a CSG operand): every render of the scene runs the reference-order kernel with the general
+                             // evaluation (rt_shapes.h csg_survivors_general) — several times slower, never refused
   bool has_csg = false;  // the scene holds CSG objects: the trace kernels built with their evaluation are launched
   bool has_walks = true; // some primitive's closest hit is followed by the container walk (DevScene::prim_flags)
   int n_cus = 256;
@@ -1211,12 +1216,12 @@ uint32_t max_roots(const rt_scene_desc* d, uint32_t prim) {
 // (RT_CSG_LIST_MAX roots per outermost CSG object in the worst case, so a render can never overflow its hit list; group
 // operands of at most RT_CSG_GROUP_STACK pending sub-groups, with no CSG object inside them).  Iterative: the input may be
 // arbitrarily deep, and nothing may overflow the host stack on behalf of a malformed scene.
-int check_graph(const rt_scene_desc* d) {
+int check_graph(const rt_scene_desc* d, bool* general) {
   const uint32_t N = d->n_nodes, C = d->n_csgs;
   std::vector<uint8_t> seen(N + C, 0);  // 0 not visited, 1 on the current path, 2 done
   std::vector<uint8_t> mesh_seen(d->n_meshes, 0);
   struct Frame {
-    uint32_t v, next, csg_depth;
+    uint32_t v, next, csg_depth, group_nest;  // group_nest: groups that are CSG operands on the path (one walk frame each)
     bool in_csg, in_csg_group;
     uint64_t roots;  // worst-case roots of the primitives below (kept inside CSG objects only)
   };
@@ -1224,16 +1229,15 @@ int check_graph(const rt_scene_desc* d) {
   auto n_children = [&](uint32_t v) { return v < N ? d->node_child_begin[v + 1] - d->node_child_begin[v] : 2u; };
   auto child = [&](uint32_t v, uint32_t k) { return v < N ? d->child_ref[d->node_child_begin[v] + k] : (k == 0 ? d->csg_left[v - N] : d->csg_right[v - N]); };
   seen[0] = 1;
-  path.push_back({0u, 0u, 0u, false, false, 0ull});
+  path.push_back({0u, 0u, 0u, 0u, false, false, 0ull});
   while (!path.empty()) {
     Frame& f = path.back();
     if (f.next == n_children(f.v)) {
       Frame done = f;
       seen[done.v] = 2;
       path.pop_back();
-      if (done.v >= N && done.csg_depth == 0 && done.roots > RT_CSG_LIST_MAX)
-        return fail(RT_ERR_UNSUPPORTED, "a CSG object can produce " + std::to_string(done.roots) + " intersections per ray; the device keeps " +
-                                            std::to_string(RT_CSG_LIST_MAX) + " (RT_CSG_LIST_MAX)");
+      // (more than the production kernels' list holds: the general evaluation, whose longer list is checked while it runs)
+      if (done.v >= N && done.csg_depth == 0 && done.roots > RT_CSG_LIST_MAX) *general = true;
       if (!path.empty() && path.back().in_csg) path.back().roots += done.roots;
       continue;
     }
@@ -1250,16 +1254,18 @@ int check_graph(const rt_scene_desc* d) {
     uint32_t u = kind == RT_REF_NODE ? idx : N + idx;
     if (seen[u] == 1) return fail(RT_ERR_INVALID_ARGUMENT, "the object graph has a cycle (a group or CSG object contains itself)");
     if (seen[u] == 2) return fail(RT_ERR_INVALID_ARGUMENT, "a group or CSG object is referenced more than once");
-    Frame g = {u, 0u, f.csg_depth, f.in_csg, f.in_csg_group, 0ull};
+    Frame g = {u, 0u, f.csg_depth, f.group_nest, f.in_csg, f.in_csg_group, 0ull};
     if (kind == RT_REF_CSG) {
-      if (f.in_csg_group)
-        return fail(RT_ERR_UNSUPPORTED, "a CSG object inside a group that is a CSG operand is not supported on the device");
+      if (f.in_csg_group) *general = true;  // (csg.rs:113-115 inside group.rs:171-201 inside csg.rs: the general evaluation)
       if (d->csg_depth[idx] != (f.in_csg ? f.csg_depth + 1 : 0u))
         return fail(RT_ERR_INVALID_ARGUMENT, "csg_depth does not match the nesting of the CSG objects");
       g.csg_depth = d->csg_depth[idx];
       g.in_csg = true;
+      g.in_csg_group = false;
     } else if (f.in_csg) {
       g.in_csg_group = true;
+      if (f.v >= N && ++g.group_nest > RT_CSG_GROUP_NEST)  // (the group is an operand itself: a walk of its own)
+        return fail(RT_ERR_UNSUPPORTED, "groups as CSG operands nested deeper than RT_CSG_GROUP_NEST (4) are not supported on the device");
     }
     seen[u] = 1;
     path.push_back(g);  // (f is dangling from here on)
@@ -1269,7 +1275,8 @@ int check_graph(const rt_scene_desc* d) {
   return RT_OK;
 }
 
-int validate(const rt_scene_desc* d) {
+int validate(const rt_scene_desc* d, bool* general) {
+  *general = false;
   if (!d) return fail(RT_ERR_INVALID_ARGUMENT, "scene is NULL");
   if (d->abi_version != RT_ABI_VERSION) return fail(RT_ERR_INVALID_ARGUMENT, "rt_scene_desc.abi_version mismatch");
   if (d->n_nodes == 0 || !d->node_bbox || !d->node_child_begin)
@@ -1331,10 +1338,11 @@ int validate(const rt_scene_desc* d) {
       return fail(RT_ERR_UNSUPPORTED, "a device-resident mesh as a CSG operand is not supported");
     if (d->csg_op[i] > RT_CSG_DIFFERENCE) return fail(RT_ERR_INVALID_ARGUMENT, "unknown csg op");
     if (!ref_ok(d, d->csg_left[i]) || !ref_ok(d, d->csg_right[i])) return fail(RT_ERR_INVALID_ARGUMENT, "csg child out of range");
-    if (d->csg_depth[i] >= RT_CSG_NEST_MAX)
-      return fail(RT_ERR_UNSUPPORTED, "CSG objects nested deeper than RT_CSG_NEST_MAX (4) are not supported on the device");
+    if (d->csg_depth[i] >= RT_CSG_GEN_NEST_MAX)
+      return fail(RT_ERR_UNSUPPORTED, "CSG objects nested deeper than RT_CSG_GEN_NEST_MAX (12) are not supported on the device");
+    if (d->csg_depth[i] >= RT_CSG_NEST_MAX) *general = true;
   }
-  return check_graph(d);
+  return check_graph(d, general);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1856,7 +1864,14 @@ int launch_render_once(const rt_scene* scene, const rt_camera* cam, const rt_opt
 #define RT_LAUNCH_TILES(STATS, REFORDER)                                                                                     \
   hipLaunchKernelGGL((render_tiles_kernel<STATS, REFORDER>), dim3(grid), dim3(64), 0, stream, scene->dev, *cam, dopt, part, \
                      n_parts, tiles_x, n_owned, packed, d_out, scene->d_stats, scene->d_overflow)
-    if (opt->reference_order) {
+    if (scene->general_csg) {
+      if (stats)
+        hipLaunchKernelGGL((render_tiles_kernel<true, true, true>), dim3(grid), dim3(64), 0, stream, scene->dev, *cam, dopt, part, n_parts,
+                           tiles_x, n_owned, packed, d_out, scene->d_stats, scene->d_overflow);
+      else
+        hipLaunchKernelGGL((render_tiles_kernel<false, true, true>), dim3(grid), dim3(64), 0, stream, scene->dev, *cam, dopt, part, n_parts,
+                           tiles_x, n_owned, packed, d_out, scene->d_stats, scene->d_overflow);
+    } else if (opt->reference_order) {
       if (stats) RT_LAUNCH_TILES(true, true);
       else RT_LAUNCH_TILES(false, true);
     } else if (opt->pipeline == RT_PIPELINE_SINGLE_KERNEL) {
@@ -2188,7 +2203,8 @@ int rt_scene_create(const rt_scene_desc* d, rt_scene** out) try {
   };
   if (!out) return fail(RT_ERR_INVALID_ARGUMENT, "out is NULL");
   *out = nullptr;
-  int rc = validate(d);
+  bool general_csg = false;
+  int rc = validate(d, &general_csg);
   if (rc) return rc;
   lap("validated");
 
@@ -2502,6 +2518,7 @@ int rt_scene_create(const rt_scene_desc* d, rt_scene** out) try {
   sc->dev.n_prims = (uint32_t)(d->n_prims + mesh_tris_total);
   sc->n_lights = d->n_lights;
   sc->has_csg = d->n_csgs > 0;
+  sc->general_csg = general_csg;
   sc->shape = ((uint64_t)(d->n_prims + mesh_tris_total) << 40) ^ ((uint64_t)d->n_nodes << 20) ^ ((uint64_t)d->n_lights << 8) ^ (uint64_t)d->n_materials;
   (void)g_learned.lookup(sc->device, sc->shape, &sc->nodes_per_sample, &sc->ratio_floor);
   if (const char* e = std::getenv("RT_STREAM_NODES_PER_SAMPLE")) {  // where the adaptive ratio starts (tests start it too low)
@@ -2777,6 +2794,8 @@ int rt_render_device_noalloc(const rt_scene* scene, const rt_camera* camera, con
   if (!d_out_rgb) return fail(RT_ERR_INVALID_ARGUMENT, "output buffer is NULL");
   if (options->reference_order || options->pipeline != RT_PIPELINE_STREAM)
     return fail(RT_ERR_INVALID_ARGUMENT, "rt_render_device_noalloc renders with the streamed production pipeline only");
+  if (scene->general_csg)
+    return fail(RT_ERR_UNSUPPORTED, "rt_render_device_noalloc: this scene's CSG objects need the general evaluation, which only the allocating entry points run");
   char* base = (char*)scene->noalloc_scratch;
   if (!base) return fail(RT_ERR_DEVICE, "the static scratch array could not be located on this device (hipGetSymbolAddress)");
   hipStream_t st = (hipStream_t)hip_stream;
@@ -2864,7 +2883,10 @@ int rt_trace_rays(const rt_scene* scene, const rt_options* options, uint32_t n, 
       rc = fail(RT_ERR_DEVICE, "upload of rays failed");
       break;
     }
-    if (options->reference_order) {
+    if (scene->general_csg) {
+      hipLaunchKernelGGL((trace_rays_kernel<true, true>), dim3((n + 63) / 64), dim3(64), 0, 0, scene->dev, dev_options(options), n, d_o, d_d,
+                         d_c, scene->d_overflow);
+    } else if (options->reference_order) {
       hipLaunchKernelGGL(trace_rays_kernel<true>, dim3((n + 63) / 64), dim3(64), 0, 0, scene->dev, dev_options(options), n, d_o, d_d,
                          d_c, scene->d_overflow);
     } else if (options->pipeline == RT_PIPELINE_SINGLE_KERNEL) {

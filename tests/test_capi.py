@@ -91,16 +91,27 @@ def test_scene_graph_with_a_cycle_or_a_shared_group_is_rejected():
 
 
 def test_csg_limits_are_checked_at_scene_creation():
-    """The device keeps RT_CSG_LIST_MAX = 16 intersections per outermost CSG evaluation: a CSG object whose primitives can
-    produce more is refused at rt_scene_create (never a silent overflow during a render); csg_depth must be the real
-    nesting; a CSG object below a group operand is unsupported."""
+    """What bounds CSG objects on the device is checked by rt_scene_create, before anything touches the device: CSG objects
+    nested at most RT_CSG_GEN_NEST_MAX = 12 deep, groups as CSG operands at most RT_CSG_GROUP_NEST = 4 deep, csg_depth the
+    real nesting.  (More than RT_CSG_LIST_MAX = 16 intersections per object, nesting beyond 4 and a CSG object below a group
+    operand are no longer refused: such scenes take the general evaluation, tests/test_gpu_parity.py and test_hostemu.py.)"""
     from conftest import N, S, translation
-    # a group of 9 spheres as an operand: 18 possible roots + 2 of the cube
+    # CSG objects nested 13 deep
+    sb1 = S.SceneBuilder()
+    obj = sb1.primitive(N.SPHERE)
+    for k in range(13):
+        obj = sb1.csg(N.CSG_UNION, obj, sb1.primitive(N.CUBE, None, translation(0.1 * k, 0., 0.)))
+    sb1.add_object(obj)
+    rc, msg = _create(sb1.flatten(build_bvh=False).desc)
+    assert rc == -2 and "RT_CSG_GEN_NEST_MAX" in msg
+    # groups as CSG operands nested 5 deep
     sb2 = S.SceneBuilder()
-    many2 = sb2.group([sb2.primitive(N.SPHERE, None, translation(0.2 * k, 0., 0.)) for k in range(9)])
-    sb2.add_object(sb2.csg(N.CSG_UNION, many2, sb2.primitive(N.CUBE)))
+    obj = sb2.primitive(N.SPHERE)
+    for k in range(5):
+        obj = sb2.csg(N.CSG_UNION, sb2.group([obj]), sb2.primitive(N.CUBE, None, translation(0.1 * k, 0., 0.)))
+    sb2.add_object(obj)
     rc, msg = _create(sb2.flatten(build_bvh=False).desc)
-    assert rc == -2 and "RT_CSG_LIST_MAX" in msg
+    assert rc == -2 and "RT_CSG_GROUP_NEST" in msg
     # wrong csg_depth
     sb3 = S.SceneBuilder()
     sb3.add_object(sb3.csg(N.CSG_DIFFERENCE, sb3.csg(N.CSG_UNION, sb3.primitive(N.SPHERE), sb3.primitive(N.CUBE)), sb3.primitive(N.SPHERE)))
@@ -108,9 +119,4 @@ def test_csg_limits_are_checked_at_scene_creation():
     assert sorted(flat3.array("csg_depth")) == [0, 1]
     rc, msg = _create(_patched(flat3, csg_depth=[0, 0])[0])
     assert rc == -1 and "csg_depth" in msg
-    # a CSG object inside a group that is a CSG operand
-    sb4 = S.SceneBuilder()
-    g = sb4.group([sb4.csg(N.CSG_UNION, sb4.primitive(N.SPHERE), sb4.primitive(N.CUBE))])
-    sb4.add_object(sb4.csg(N.CSG_INTERSECTION, g, sb4.primitive(N.SPHERE)))
-    rc, msg = _create(sb4.flatten(build_bvh=False).desc)
-    assert rc == -2 and "CSG object inside a group" in msg
+

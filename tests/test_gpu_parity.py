@@ -788,19 +788,48 @@ def test_csg_nested_three_deep_vs_oracle():
     sc.close()
 
 
-def test_csg_below_a_group_that_is_a_csg_operand_is_refused_loudly():
-    """The one CSG construction the device does not evaluate (DESIGN.md "Limits"): a CSG object inside a GROUP that is itself
-    a CSG operand.  The reference renders it (csg.rs:113-115 + group.rs:171-201); here rt_scene_create says so — status and
-    message — instead of rendering something else."""
-    sb = S.SceneBuilder()
-    inner = sb.csg(N.CSG_UNION, sb.primitive(N.SPHERE), sb.primitive(N.CUBE, None, translation(0.5, 0., 0.)))
-    grp = sb.group([inner, sb.primitive(N.SPHERE, None, translation(-0.5, 0., 0.))])
-    sb.add_object(sb.csg(N.CSG_DIFFERENCE, grp, sb.primitive(N.SPHERE, None, translation(0., 0.8, 0.))))
-    sb.add_light((-4., 6., -6.), (1., 1., 1.))
-    flat = sb.flatten(build_bvh=False)
+@pytest.mark.parametrize("which", [0, 1, 2])
+@pytest.mark.parametrize("build_bvh", [False, True])
+def test_csg_beyond_the_production_kernels_takes_the_general_evaluation(which, build_bvh):
+    """The reference's CSG objects are unbounded (csg.rs:87-122: a Vec per temporary collector, plain recursion).  What the
+    production kernels do not evaluate — more than RT_CSG_LIST_MAX intersections per object, nesting deeper than
+    RT_CSG_NEST_MAX, a CSG object inside a group that is a CSG operand — is not refused: every render of such a scene runs
+    the reference-order kernel with the general evaluation (csg_survivors_general).  Pixels (with and without counters, whole
+    and as parts) and random rays equal the oracle's."""
+    import csg_scenes
+    name, make = csg_scenes.GENERAL[which]
+    flat = make().flatten(build_bvh=build_bvh)
+    cam = S.make_camera(96, 72, 1.0, S.view_transformation((1.5, 1.5, -5.), (0., 0., 0.), (0., 1., 0.)))
+    opt = S.make_options(2, 5, True)
+    want, _ = O.render(flat, cam, opt)
+    assert (want.sum(axis=2) > 0).sum() > 300, name
+    got, st = R.render(flat, cam, opt)
+    assert float(np.abs(got - want).max()) < F64_TOL, name
+    got2, _ = R.render(flat, cam, opt, want_stats=False)
+    assert np.array_equal(got, got2)
+    u8, _ = R.render_u8(flat, cam, opt)
+    assert np.array_equal(u8, O.quantize(got))
+    rng = np.random.default_rng(3)
+    origins = rng.uniform(-3, 3, (1024, 3))
+    dirs = rng.normal(size=(1024, 3))
+    dirs /= np.linalg.norm(dirs, axis=1, keepdims=True)
+    ropt = S.make_options(1, 4, True)
+    sc = R.DeviceScene(flat)
+    rays = sc.trace_rays(ropt, origins, dirs)
+    want_rays = np.stack([O.color_at(flat, ropt, o, d) for o, d in zip(origins, dirs)])
+    assert float(np.abs(rays - want_rays).max()) < F64_TOL, name
+    sc.close()
+
+
+def test_general_csg_list_overflow_is_reported():
+    """The general evaluation keeps RT_CSG_BIG_LIST = 256 intersections alive per outermost object; a ray that produces more
+    sets a flag and the render fails with RT_ERR_OVERFLOW (-4) instead of returning pixels of a truncated list."""
+    import csg_scenes
+    flat = csg_scenes.many_hits(150).flatten(build_bvh=False)  # up to 302 intersections along the row of spheres
+    cam = S.make_camera(64, 16, 0.6, S.view_transformation((-6., 0., 0.), (0., 0., 0.), (0., 1., 0.)))
     with pytest.raises(R.RtError) as e:
-        R.DeviceScene(flat)
-    assert e.value.code == -2 and "CSG object inside a group that is a CSG operand" in str(e.value)
+        R.render(flat, cam, S.make_options(1, 2, True))
+    assert e.value.code == -4
 
 
 def test_f32_box_test_never_culls_what_the_exact_test_keeps():

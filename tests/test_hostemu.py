@@ -1,6 +1,7 @@
 """The host-emulation build of the render core (tools/hostemu: csrc/rtcore.hip compiled as host C++, one lane at a time,
 under UBSan) against the oracle — on the CPU, so that the RT_HOST_EMU bodies in csrc/ (one-lane stand-ins for the wave-level
-helpers, the serial shade loop) cannot drift from what the kernels compute, and so that undefined behaviour in the device code
+helpers, the serial shade loop) cannot drift from what the kernels compute, the general CSG evaluation is exercised where a
+sanitizer can watch it, and so that undefined behaviour in the device code
 (shifts, misaligned or out-of-range accesses, signed overflow) is seen without a GPU sanitizer.
 
 The emulated library is a debugging harness: it is built into build/ and loaded only by the child process of this test
@@ -42,6 +43,21 @@ for rel, size, depth, ss in cases:
         print(rel, name, d, flush=True)
         if not d < 1e-9:
             sys.exit(4)
+# CSG constructions that only the general evaluation handles (tests/csg_scenes.py)
+sys.path.insert(0, os.path.join(sys.argv[1], "tests"))
+import csg_scenes
+from raytracer_amd.harness import scene as S
+cam = S.make_camera(40, 30, 1.0, S.view_transformation((1.5, 1.5, -5.), (0., 0., 0.), (0., 1., 0.)))
+for name, make in csg_scenes.GENERAL:
+    for bvh in (False, True):
+        flat = make().flatten(build_bvh=bvh)
+        opt = S.make_options(1, 4, True)
+        want, _ = O.render(flat, cam, opt)
+        got, _ = R.render(flat, cam, opt)
+        d = float(np.abs(got - want).max())
+        print(name, bvh, d, int((want.sum(axis=2) > 0).sum()), flush=True)
+        if not d < 1e-9 or not (want.sum(axis=2) > 0).sum() > 50:
+            sys.exit(5)
 print("OK")
 """
 
