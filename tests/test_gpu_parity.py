@@ -900,3 +900,20 @@ def test_f32_box_test_never_culls_what_the_exact_test_keeps():
             # (and it still culls: the test is not "keep everything")
             assert (f32_path & ((out & 1) == 0)).sum() > 0 or kind[2] == "clamped"
     assert total_kept > 100000
+
+
+def test_shutdown_releases_what_the_library_keeps_and_it_stays_usable():
+    """rt_shutdown (library housekeeping, no counterpart in the reference): the pooled device blocks and pinned staging go
+    back to the driver — free device memory rises by at least the workspace a render left in the pool — and the next render
+    simply allocates again, same pixels."""
+    import torch
+    rs = Y.load_scene(os.path.join(GOLDEN, "scenes", "images/chapters/reflections.yml"), width=256, height=192, depth=4, supersampling_level=2)
+    flat = rs.builder.flatten()
+    a, _ = R.render(flat, rs.camera, rs.options(), want_stats=False)  # (one-shot: its scene's blocks end up in the pool)
+    torch.cuda.synchronize()
+    free0, _ = torch.cuda.mem_get_info()
+    N.core_lib().rt_shutdown()
+    free1, _ = torch.cuda.mem_get_info()
+    assert free1 > free0
+    b, _ = R.render(flat, rs.camera, rs.options(), want_stats=False)
+    assert np.array_equal(a, b)
