@@ -815,6 +815,16 @@ def test_csg_beyond_the_production_kernels_takes_the_general_evaluation(which, b
     dirs /= np.linalg.norm(dirs, axis=1, keepdims=True)
     ropt = S.make_options(1, 4, True)
     sc = R.DeviceScene(flat)
+    # three cyclic tile parts (what three ranks render), assembled on the device
+    torch = _torch()
+    n_max = D.tile_count(cam.width, cam.height, 0, 3)
+    bufs = torch.zeros((3, n_max * 64 * 3), dtype=torch.float64, device="cuda")
+    for p in range(3):
+        sc.render_tiles(cam, opt, p, 3, bufs[p].data_ptr())
+    out = torch.empty((cam.height, cam.width, 3), dtype=torch.float64, device="cuda")
+    R.assemble_tiles(cam.width, cam.height, 3, n_max, bufs.data_ptr(), out.data_ptr())
+    torch.cuda.synchronize()
+    assert np.array_equal(out.cpu().numpy(), got), name
     rays = sc.trace_rays(ropt, origins, dirs)
     want_rays = np.stack([O.color_at(flat, ropt, o, d) for o, d in zip(origins, dirs)])
     assert float(np.abs(rays - want_rays).max()) < F64_TOL, name
