@@ -831,6 +831,22 @@ def test_csg_beyond_the_production_kernels_takes_the_general_evaluation(which, b
     sc.close()
 
 
+def test_random_nested_csg_scenes_vs_oracle():
+    """Forty seeded random trees of CSG objects, groups and primitives (tests/csg_scenes.py): whichever evaluation each one
+    takes, the pixels are the oracle's."""
+    import csg_scenes
+    cam = S.make_camera(48, 36, 1.0, S.view_transformation((1.5, 1.5, -6.), (0., 0., 0.), (0., 1., 0.)))
+    opt = S.make_options(1, 3, True)
+    seen = 0
+    for seed in range(40):
+        flat = csg_scenes.random_nested(seed).flatten(build_bvh=bool(seed % 2))
+        want, _ = O.render(flat, cam, opt)
+        got, _ = R.render(flat, cam, opt, want_stats=False)
+        assert float(np.abs(got - want).max()) < F64_TOL, seed
+        seen += int((want.sum(axis=2) > 0).sum() > 100)
+    assert seen >= 30
+
+
 def test_general_csg_list_overflow_is_reported():
     """The general evaluation keeps RT_CSG_BIG_LIST = 256 intersections alive per outermost object; a ray that produces more
     sets a flag and the render fails with RT_ERR_OVERFLOW (-4) instead of returning pixels of a truncated list."""

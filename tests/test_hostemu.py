@@ -58,6 +58,16 @@ for name, make in csg_scenes.GENERAL:
         print(name, bvh, d, int((want.sum(axis=2) > 0).sum()), flush=True)
         if not d < 1e-9 or not (want.sum(axis=2) > 0).sum() > 50:
             sys.exit(5)
+cam = S.make_camera(28, 21, 1.0, S.view_transformation((1.5, 1.5, -6.), (0., 0., 0.), (0., 1., 0.)))
+for seed in range(24):  # seeded random trees of CSG objects, groups and primitives
+    flat = csg_scenes.random_nested(seed).flatten(build_bvh=bool(seed % 2))
+    opt = S.make_options(1, 3, True)
+    want, _ = O.render(flat, cam, opt)
+    got, _ = R.render(flat, cam, opt)
+    d = float(np.abs(got - want).max())
+    if not d < 1e-9:
+        print("random_nested", seed, d, flush=True)
+        sys.exit(6)
 print("OK")
 """
 
