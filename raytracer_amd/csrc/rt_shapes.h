@@ -306,11 +306,13 @@ __device__ __forceinline__ void csg_add_group(const DevScene& s, uint32_t entry,
 // closest positive t), a GROUP frame is a suspended intersect_iter (its pending sub-groups in a pool shared by the nested
 // group frames, its cursor in the child list being walked) feeding the collector of the nearest CSG frame below it.
 // Bounds, all checked by rt_scene_create except the list (a run-time flag -> RT_ERR_OVERFLOW): RT_CSG_BIG_LIST intersections
-// alive at once, RT_CSG_GEN_FRAMES frames, RT_CSG_GROUP_NEST nested group operands of RT_CSG_GROUP_STACK pending sub-groups.
+// alive at once, RT_CSG_GEN_FRAMES frames, RT_CSG_GROUP_NEST nested group operands of RT_CSG_BIG_GROUP_STACK pending sub-groups.
 // ---------------------------------------------------------------------------------------------
 #define RT_CSG_BIG_LIST 256
 #define RT_CSG_GEN_FRAMES 16
 #define RT_CSG_GROUP_NEST 4
+#define RT_CSG_BIG_GROUP_STACK 24  // pending sub-groups of ONE group operand in the general evaluation (a model of 2^20 triangles
+                                   // under the reference's builder is ~21 levels deep, one sibling pending per level)
 #define RT_CSG_GEN_NEST_MAX 12  // CSG objects nested at most this deep (frames = CSG frames + group frames)
 template <bool STATS>
 __device__ __forceinline__ void csg_big_add_prim(const DevScene& s, uint32_t idx, d3 o, d3 d, CsgHit* list, int& n, double& hit_time,
@@ -343,8 +345,8 @@ __device__ int csg_survivors_general(const DevScene& s, uint32_t csg_root, d3 o,
     double hit;         // CSG frame: hit_time() of its temporary collector
   };
   GFrame fr[RT_CSG_GEN_FRAMES];
-  uint32_t gs_begin[RT_CSG_GROUP_NEST * RT_CSG_GROUP_STACK], gs_count[RT_CSG_GROUP_NEST * RT_CSG_GROUP_STACK];
-  double gs_t[RT_CSG_GROUP_NEST * RT_CSG_GROUP_STACK];
+  uint32_t gs_begin[RT_CSG_GROUP_NEST * RT_CSG_BIG_GROUP_STACK], gs_count[RT_CSG_GROUP_NEST * RT_CSG_BIG_GROUP_STACK];
+  double gs_t[RT_CSG_GROUP_NEST * RT_CSG_BIG_GROUP_STACK];
   const d3 dinv = mk3(1. / d.x, 1. / d.y, 1. / d.z);  // Ray::new (ray.rs:27-34)
   int n = 0, fp = 0, gsp = 0;
   fr[0].id = csg_root;
@@ -381,7 +383,7 @@ __device__ int csg_survivors_general(const DevScene& s, uint32_t csg_root, d3 o,
     for (int k = 0; k < 6; k++) bb[k] = root->bb[k];
     if (STATS) cnt.node_visits++;
     if (!bbox_time(bb, o, dinv, t)) return;
-    if (gsp + 1 > RT_CSG_GROUP_NEST * RT_CSG_GROUP_STACK) {
+    if (gsp + 1 > RT_CSG_GROUP_NEST * RT_CSG_BIG_GROUP_STACK) {
       cnt.overflow = 1;
       return;
     }
@@ -417,7 +419,7 @@ __device__ int csg_survivors_general(const DevScene& s, uint32_t csg_root, d3 o,
         for (int k = 0; k < 6; k++) bb[k] = e->bb[k];
         if (STATS) cnt.node_visits++;
         if (bbox_time(bb, o, dinv, t)) {
-          if (gsp < RT_CSG_GROUP_NEST * RT_CSG_GROUP_STACK) {
+          if (gsp < RT_CSG_GROUP_NEST * RT_CSG_BIG_GROUP_STACK) {
             gs_begin[gsp] = e->begin;
             gs_count[gsp] = e->count;
             gs_t[gsp] = t;

@@ -2304,8 +2304,10 @@ int rt_scene_create(const rt_scene_desc* d, rt_scene** out) try {
       uint32_t ref = (*side)[i];
       if ((ref >> RT_REF_KIND_SHIFT) != RT_REF_NODE) continue;
       uint32_t g = ref & RT_REF_INDEX_MASK;
-      if (std::max(1u, stack_need(d, g, memo, 0)) > RT_CSG_GROUP_STACK)
-        return fail(RT_ERR_UNSUPPORTED, "a group that is a CSG operand nests deeper than the device walks it (RT_CSG_GROUP_STACK)");
+      const uint32_t operand_need = std::max(1u, stack_need(d, g, memo, 0));
+      if (operand_need > RT_CSG_BIG_GROUP_STACK)
+        return fail(RT_ERR_UNSUPPORTED, "a group that is a CSG operand nests deeper than the device walks it (RT_CSG_BIG_GROUP_STACK)");
+      if (operand_need > RT_CSG_GROUP_STACK) general_csg = true;  // (deeper than the production kernels walk an operand)
       DevEntry e;
       std::memset(&e, 0, sizeof(e));
       e.ref = ref;

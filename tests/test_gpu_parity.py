@@ -847,6 +847,20 @@ def test_random_nested_csg_scenes_vs_oracle():
     assert seen >= 30
 
 
+def test_model_as_csg_operand_vs_oracle():
+    """An OBJ model as a CSG operand (tests/golden/scenes/csg-dragon.yml, not a reference scene: the dragon with a ball taken
+    out of it).  build_bvh never descends into a CSG object (group.rs:144-167 recurses into groups only), so the operand is ONE
+    group of 23 490 triangles and every ray that enters its box meets all of them: far more possible intersections than the
+    production kernels' list holds — the general evaluation — and still the oracle's pixels."""
+    rs = Y.load_scene(os.path.join(GOLDEN, "scenes", "csg-dragon.yml"), width=64, height=48, depth=3, supersampling_level=1)
+    flat = rs.builder.flatten()
+    assert flat.desc.n_csgs == 1 and flat.desc.n_prims > 23000
+    want, _ = O.render(flat, rs.camera, rs.options())
+    got, _ = R.render(flat, rs.camera, rs.options(), want_stats=False)
+    assert (want.sum(axis=2) > 0).sum() > 1000
+    assert float(np.abs(got - want).max()) < F64_TOL
+
+
 def test_general_csg_list_overflow_is_reported():
     """The general evaluation keeps RT_CSG_BIG_LIST = 256 intersections alive per outermost object; a ray that produces more
     sets a flag and the render fails with RT_ERR_OVERFLOW (-4) instead of returning pixels of a truncated list."""
