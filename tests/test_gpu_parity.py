@@ -848,11 +848,11 @@ def test_random_nested_csg_scenes_vs_oracle():
 
 
 def test_model_as_csg_operand_vs_oracle():
-    """An OBJ model as a CSG operand (tests/golden/scenes/csg-dragon.yml, not a reference scene: the dragon with a ball taken
+    """An OBJ model as a CSG operand (tests/scenes/csg-dragon.yml, not a reference scene: the dragon with a ball taken
     out of it).  build_bvh never descends into a CSG object (group.rs:144-167 recurses into groups only), so the operand is ONE
     group of 23 490 triangles and every ray that enters its box meets all of them: far more possible intersections than the
     production kernels' list holds — the general evaluation — and still the oracle's pixels."""
-    rs = Y.load_scene(os.path.join(GOLDEN, "scenes", "csg-dragon.yml"), width=64, height=48, depth=3, supersampling_level=1)
+    rs = Y.load_scene(os.path.join(os.path.dirname(GOLDEN), "scenes", "csg-dragon.yml"), width=64, height=48, depth=3, supersampling_level=1)
     flat = rs.builder.flatten()
     assert flat.desc.n_csgs == 1 and flat.desc.n_prims > 23000
     want, _ = O.render(flat, rs.camera, rs.options())
