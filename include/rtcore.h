@@ -287,7 +287,9 @@ void rt_scene_destroy(rt_scene* scene);
  *                    group on the device, bit for bit the tree build_bvh builds (same candidate planes, same strict
  *                    comparisons, stable partitions), and lays it out for the kernels.
  * A posed mesh belongs to ONE scene at a time: pose, create the scene, and only then pose for the next frame (the scene has
- * its own copy of everything by then).  Not thread-safe per mesh. */
+ * its own copy of everything by then).  Not thread-safe per mesh.  A mesh lives on the device that was current when it was
+ * created: a scene that refers to it is created on that device (rt_options.n_devices > 1 with meshes is refused with
+ * RT_ERR_INVALID_ARGUMENT; a host with several GPUs keeps one mesh per device and model). */
 typedef struct rt_mesh rt_mesh;
 typedef struct rt_mesh_desc {
   uint32_t n_tris;
