@@ -1567,6 +1567,11 @@ int ensure_workspace(const rt_scene* sc, uint64_t want_samples, uint32_t* batch_
       // every one-shot render of a large frame free and re-allocate its 50-GB workspace once free memory had dropped to
       // three times the need: 1.4 s per call.)
       size_t budget = (free_b + g_device_pool.cached) / 3 + sc->ws_bytes;
+      // (a host that shares the device with others caps it: more, smaller batches, the same pixels)
+      if (const char* e = std::getenv("RT_WORKSPACE_MAX_BYTES")) {
+        const unsigned long long cap = std::strtoull(e, nullptr, 10);
+        if (cap >= (64ull << 20)) budget = std::min<size_t>(budget, (size_t)cap);
+      }
       while (need > budget && n > 4096) {
         n = align_up(n / 2, 64);
         need = carve_workspace(nullptr, nullptr, n, ratio, sc->n_lights);

@@ -957,3 +957,24 @@ def test_shutdown_releases_what_the_library_keeps_and_it_stays_usable():
     assert free1 > free0
     b, _ = R.render(flat, rs.camera, rs.options(), want_stats=False)
     assert np.array_equal(a, b)
+
+
+def test_workspace_cap_changes_batches_not_pixels(monkeypatch):
+    """RT_WORKSPACE_MAX_BYTES (a host that shares the device): the frame is rendered in more, smaller batches; same pixels."""
+    torch = _torch()
+    rs = Y.load_scene(scene_path("images", "chapters/reflections"), width=640, height=480, depth=4, supersampling_level=2)
+    flat = rs.builder.flatten()
+    a = R.DeviceScene(flat)
+    whole = torch.empty((480, 640, 3), dtype=torch.float64, device="cuda")
+    a.render_device(rs.camera, rs.options(), whole.data_ptr())
+    torch.cuda.synchronize()
+    a.close()
+    N.core_lib().rt_release_cached_memory()
+    monkeypatch.setenv("RT_WORKSPACE_MAX_BYTES", str(96 << 20))
+    b = R.DeviceScene(flat)
+    capped = torch.empty_like(whole)
+    b.render_device(rs.camera, rs.options(), capped.data_ptr())
+    torch.cuda.synchronize()
+    b.close()
+    N.core_lib().rt_release_cached_memory()
+    assert torch.equal(whole, capped)
