@@ -56,7 +56,7 @@ unsafe extern "C" fn bump_progress(pixels_done: u64, user: *mut std::ffi::c_void
 // ---------------------------------------------------------------------------------------------------------------------
 // Animations (animation_renderer.rs:61-66, 98-121): frame i is rendered from scene.animate(time) = clone + animate +
 // compute_bvh (scene.rs:30-36).  For a model of thousands of triangles that preparation is 10x the GPU render, so the model's
-// group lives on the device (include/rtcore.h "rt_mesh"): GpuMeshes is created once per animation, its `pose` stands in for
+// group lives on the device (include/rtcore.h "rt_mesh"): a GpuMesh per model is created once per animation, its `pose` stands in for
 // the per-triangle part of ObjectGroup::transform + recalculate_bbox, and FlatScene emits the group as ONE RT_REF_MESH
 // child.  rt_scene_create then builds the group's subtree on the device — the tree build_bvh would have built, bit for bit.
 
