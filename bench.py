@@ -36,6 +36,7 @@ WORKLOADS = {
     "dragons_800_ss2_d5": ("tests/golden/scenes/images/general/dragons.yml", 800, 800, 2, 5),
     "dragon_800_ss2_d5": ("scenes/dragon.yml", 800, 800, 2, 5),
     "csg_lens_800_ss2_d8": ("tests/golden/scenes/animations/general/csg-lens.yml", 800, 800, 2, 8),
+    "refractions_800_ss2_d8": ("tests/golden/scenes/images/chapters/refractions.yml", 800, 800, 2, 8),
     "readme_800_ss2_d5": ("scenes/readme.yml", 800, 800, 2, 5),
 }
 
