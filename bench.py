@@ -151,9 +151,16 @@ def main():
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    torch.cuda.set_device(local_rank)
+    # Development only (a box with ONE GPU): RT_BENCH_REHEARSAL=1 runs the N > 1 control flow with every rank on device 0 and
+    # gloo (through host buffers) in place of RCCL.  Its timings mean nothing and it says so in the line it prints.
+    rehearsal = world > 1 and os.environ.get("RT_BENCH_REHEARSAL") == "1"
+    device_index = 0 if rehearsal else local_rank
+    torch.cuda.set_device(device_index)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     path, w, h, ss, depth = WORKLOADS[args.workload]
     rs = Y.load_scene(os.path.join(ROOT, path), width=w, height=h, depth=depth, supersampling_level=ss)
@@ -201,7 +208,14 @@ def main():
         else:
             launch(opt, False)
         if world > 1:
-            dist.gather(local, gather_list=bufs, dst=0)
+            if rehearsal:
+                host = local.cpu()
+                got = [torch.empty_like(host) for _ in range(world)] if rank == 0 else None
+                dist.gather(host, gather_list=got, dst=0)
+                if rank == 0:
+                    allparts.copy_(torch.stack(got))
+            else:
+                dist.gather(local, gather_list=bufs, dst=0)
             if rank == 0:
                 R.assemble_tiles(w, h, world, n_max, allparts.data_ptr(), out.data_ptr(), stream)
 
@@ -231,6 +245,14 @@ def main():
     # reference-order image
     xdiff_timed = float((target - ref_img).abs().max().item())
     del ref_img
+    assembled_same = None
+    if world > 1 and rank == 0:
+        # what the gather and the un-interleave kernel left on rank 0, against this rank rendering the whole frame by itself
+        whole = torch.empty((h, w, 3), dtype=torch.float64, device="cuda")
+        scene.render_device(cam, opt, whole.data_ptr(), stream, want_stats=False)
+        torch.cuda.synchronize()
+        assembled_same = bool(torch.equal(whole, out))
+        del whole
 
     one_shot_ms = None
     if world == 1 and not args.no_one_shot:
@@ -326,6 +348,8 @@ def main():
              max(xdiff_counted, xdiff_timed), float(st["fallback_flags"])]
     vec = torch.tensor([float(st[k]) for k in keys] + [mean(k) for k in tkeys] + extra, dtype=torch.float64, device="cuda")
     if world > 1:
+        if rehearsal:
+            vec = vec.cpu()
         allv = [torch.empty_like(vec) for _ in range(world)]
         dist.all_gather(allv, vec)
         allv = torch.stack(allv).cpu()
@@ -372,7 +396,9 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": t_max / args.steps * 1e3,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"{args.workload}: {os.path.basename(path)} {w}x{h} supersampling {ss} depth {depth}",
-                       "partition": "single GPU, whole frame" if world == 1 else f"8x8 tiles cyclic over {world} GPUs + gather to rank 0",
+                       "partition": "single GPU, whole frame" if world == 1 else
+                                    (f"REHEARSAL (not a measurement): {world} ranks on ONE device, gloo through host buffers" if rehearsal else
+                                     f"8x8 tiles cyclic over {world} GPUs + gather to rank 0"),
                        "rays_per_frame": rays, "primary": tot["rays_primary"], "shadow": tot["rays_shadow"],
                        "reflect": tot["rays_reflect"], "refract": tot["rays_refract"],
                        "shadow_rays_not_traced_light_behind_surface": tot["rays_shadow_culled"],
@@ -409,6 +435,7 @@ def main():
                                  "stream; traffic / hbm / l2 from the PMC passes of the same workload (profiles/)"},
             "parity": {"max_abs_diff_vs_reference_order_render": float(allv[:, ex + 4].max()),
                        "fallback_flags": int(allv[:, ex + 5].sum()),
+                       "assembled_frame_equals_one_gpu_render": assembled_same,
                        "note": "full-size cross-check, f64 pixels: the image left by the TIMED kernels (no counters) and the image of "
                                "the counting launch, each against the reference-order traversal's"},
         }
