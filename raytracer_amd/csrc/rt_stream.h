@@ -127,19 +127,52 @@ __device__ __forceinline__ uint32_t wave_take(uint32_t* counter, bool want) {
 #ifndef RT_XCD_GUIDE
 #define RT_XCD_GUIDE 1u  // guided grabs: the next grab is 2 / RT_XCD_GUIDE of what is left of the share per wavefront of the XCD
 #endif
+// What a grab costs (round 3, profiles/r03f_drain_instrumentation.txt): a returning device-scope atomic is a ~2 us round trip
+// during which the whole wavefront — the lanes still traversing included — stands still, and the guided end phase of every
+// launch was ~3000 of them per counter, 64 rays at a time: 10-40 % of a wavefront's life in a launch of 1-16 M rays.  Hence
+// the floor of 256 and 4 turns instead of 8 (floor 0 / 128 / 192 / 256 / 384 / 512 / 1024 at 8 turns, then 2 / 4 turns:
+// part of 8 of the 4K frame 5.00 / 4.95 / - / 4.90 / - / 4.94 / 5.19 -> 4.82 ms at 256 and 4; csg-lens 800x800 8.07 -> 7.62 ms).
+#ifndef RT_XCD_MIN_GRAB
+#define RT_XCD_MIN_GRAB 256u  // floor of the guided grab (a thin launch's is the wavefront's lanes_in_use)
+#endif
 #ifndef RT_XCD_TURNS
-#define RT_XCD_TURNS 8u  // a wavefront's grab is sized so that it gets at least this many
+#define RT_XCD_TURNS 4u  // a wavefront's grab is sized so that it gets at least this many
 #endif
 struct XcdCursor {
   uint32_t xcd, victim, next, end;  // [next, end): items of XCD (xcd + victim) & 7's share this wavefront has taken
   uint32_t grab;                    // items per atomic: 64 .. RT_XCD_GRAB, so that every wavefront still gets several turns
   uint32_t done;                    // bit x: XCD x's share is known to be used up
   uint32_t lanes;                   // lanes_in_use: the smallest grab
+  uint32_t flat;                    // 1: [next, end) are item ids themselves (a launch without counters, below)
+  uint32_t first;                   // RT_XCD_STATIC_FIRST: the first grab's size (every wavefront's first range is its own by position)
 };
+// A launch with at most one group of `lanes` items per wavefront uses NO counters: wavefront i owns items [i * lanes, (i + 1) * lanes).
+// (Measured, profiles/r03f_drain_instrumentation.txt: in such a launch a wavefront spent 50-97 % of its life in the hand-out, and
+// one that found nothing lived 37 us walking the eight counters — returning device-scope atomics are ~2 us round trips.)
+#ifndef RT_XCD_FLAT
+#define RT_XCD_FLAT 1
+#endif
+#ifndef RT_XCD_STATIC_FIRST
+#define RT_XCD_STATIC_FIRST 1
+#endif
+__device__ __forceinline__ uint32_t xcd_share(uint32_t n_items, uint32_t xx);
 __device__ __forceinline__ XcdCursor xcd_cursor(uint32_t n_items, uint32_t lanes = 64u) {
+  if (RT_XCD_FLAT && (unsigned long long)gridDim.x * lanes >= n_items) {
+    const uint32_t begin = (uint32_t)min((unsigned long long)blockIdx.x * lanes, (unsigned long long)n_items), end = min(begin + lanes, n_items);
+    return XcdCursor{0u, begin == end ? 8u : 0u, begin, end, 0u, 0xFFu, lanes, 1u, 0u};
+  }
   uint32_t grab = lanes;
   while (grab >= 64u && grab < RT_XCD_GRAB && (unsigned long long)grab * gridDim.x * RT_XCD_TURNS < n_items) grab <<= 1;
-  return XcdCursor{blockIdx.x & 7u, 0u, 0u, 0u, grab, 0u, lanes};
+#if RT_XCD_STATIC_FIRST
+  // the first range of a wavefront is its own by position — wavefront j of XCD x owns positions [j * grab, (j + 1) * grab) of
+  // x's share — and the counters hand out what lies behind those (xcd_static): no launch starts with every wavefront's atomic
+  // on eight addresses
+  const uint32_t xx = blockIdx.x & 7u, j = blockIdx.x >> 3, share = xcd_share(n_items, xx);
+  const uint32_t begin = j < gridDim.x / 8u ? (uint32_t)min((unsigned long long)j * grab, (unsigned long long)share) : share;
+  return XcdCursor{xx, 0u, begin, min(begin + grab, share), grab, 0u, lanes, 0u, grab};
+#else
+  return XcdCursor{blockIdx.x & 7u, 0u, 0u, 0u, grab, 0u, lanes, 0u, 0u};
+#endif
 }
 
 // A launch with few items (the deep levels of a frame, a small image, one GPU's part of a frame split eight ways) is bound by
@@ -167,6 +200,11 @@ __device__ __forceinline__ uint32_t xcd_share(uint32_t n_items, uint32_t xx) {
   uint32_t mine = (n_chunks - xx + 7u) / 8u, share = mine * RT_XCD_CHUNK;
   if ((n_chunks - 1u) % 8u == xx) share -= n_chunks * RT_XCD_CHUNK - n_items;  // the ragged last chunk is this XCD's
   return share;
+}
+
+// Positions at the start of XCD xx's share that its wavefronts own by position (xcd_cursor); the counter counts from there.
+__device__ __forceinline__ uint32_t xcd_static(uint32_t share, uint32_t first) {
+  return (uint32_t)min((unsigned long long)(gridDim.x / 8u) * first, (unsigned long long)share);
 }
 
 // A wavefront's private range is up to RT_XCD_GRAB = 1024 CONSECUTIVE positions, and consecutive rays cost alike: 1024 camera rays
@@ -202,10 +240,12 @@ __device__ __forceinline__ uint32_t xcd_take(uint32_t* counters, uint32_t n_item
       uint32_t q = 0;
       if (w && rank_in(m) == 0) q = atomicAdd(&counters[xx], c.grab);
       q = __builtin_amdgcn_readfirstlane(__shfl(q, __ffsll((long long)m) - 1, 64));
+      q = (uint32_t)min((unsigned long long)q + xcd_static(share, c.first), (unsigned long long)share);
       if (q >= share) {
         // Used up.  Word 8 of the counters collects the used-up shares: when a kernel drains, every wavefront would
         // otherwise try all 8 counters, and 3072 wavefronts x 8 returning atomics on 8 addresses took ~250 us per
-        // launch, work or no work.
+        // launch, work or no work.  (Round 3: reading all eight counters in one go after a failed grab instead — lanes 0..7, one
+        // load each — was SLOWER everywhere: part of 8 5.46 -> 5.66 ms, dragon_800 2.70 -> 2.99 ms.)
         uint32_t seen = __hip_atomic_load(&counters[8], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (w && rank_in(m) == 0 && !((seen >> xx) & 1u)) atomicOr(&counters[8], 1u << xx);
         c.done |= __builtin_amdgcn_readfirstlane(__shfl(seen, __ffsll((long long)m) - 1, 64)) | (1u << xx);
@@ -217,13 +257,14 @@ __device__ __forceinline__ uint32_t xcd_take(uint32_t* counters, uint32_t n_item
       // guided: the nearer the share's end, the smaller the next grab, so that no wavefront sits on a long private range
       // while the others have run dry
       uint32_t left = share - c.end;
-      c.grab = min(max((left / max(gridDim.x * RT_XCD_GUIDE / 4u, 1u)) & ~63u, c.lanes), (uint32_t)RT_XCD_GRAB);
+      c.grab = min(max((left / max(gridDim.x * RT_XCD_GUIDE / 4u, 1u)) & ~63u, max(c.lanes, (uint32_t)RT_XCD_MIN_GRAB)), (uint32_t)RT_XCD_GRAB);
     }
     uint32_t avail = c.end - c.next, r = rank_in(m);
     if (w && r < avail) {
       uint32_t q = c.next + r;
       const uint32_t chunk0 = ((q / RT_XCD_CHUNK) * 8u + xx) * RT_XCD_CHUNK;
       id = chunk0 + ((RT_XCD_SPREAD && n_items - chunk0 >= RT_XCD_CHUNK) ? chunk_spread(q % RT_XCD_CHUNK) : q % RT_XCD_CHUNK);
+      if (c.flat) id = q;
     }
     c.next += min(avail, (uint32_t)__builtin_popcountll(m));
   }
@@ -259,6 +300,7 @@ __device__ __forceinline__ bool xcd_range(uint32_t* counters, uint32_t n_items, 
     uint32_t q = 0;
     if (first) q = atomicAdd(&counters[xx], c.grab);
     q = __builtin_amdgcn_readfirstlane(q);
+    q = (uint32_t)min((unsigned long long)q + xcd_static(share, c.first), (unsigned long long)share);
     if (q >= share) {  // used up (see xcd_take)
       uint32_t seen = __hip_atomic_load(&counters[8], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if (first && !((seen >> xx) & 1u)) atomicOr(&counters[8], 1u << xx);
@@ -269,7 +311,7 @@ __device__ __forceinline__ bool xcd_range(uint32_t* counters, uint32_t n_items, 
     c.next = q;
     c.end = min(q + c.grab, share);
     const uint32_t left = share - c.end;
-    c.grab = min(max((left / max(gridDim.x * RT_XCD_GUIDE / 4u, 1u)) & ~63u, c.lanes), (uint32_t)RT_XCD_GRAB);
+    c.grab = min(max((left / max(gridDim.x * RT_XCD_GUIDE / 4u, 1u)) & ~63u, max(c.lanes, (uint32_t)RT_XCD_MIN_GRAB)), (uint32_t)RT_XCD_GRAB);
     return true;
   }
   return false;
@@ -303,7 +345,7 @@ __device__ __forceinline__ uint32_t lit_take(const Ws& w, uint32_t* counters, ui
       const uint32_t q = c.next, n_win = min(wave, min(c.end - q, RT_XCD_CHUNK - q % RT_XCD_CHUNK));
       // (not chunk_spread: a wavefront's successive windows are neighbouring surface points facing the same light, and dealing
       // them apart cost the 4K frame's shadow rays 12.7 -> 14.1 ms)
-      win.id0 = ((q / RT_XCD_CHUNK) * 8u + xx) * RT_XCD_CHUNK + q % RT_XCD_CHUNK;
+      win.id0 = c.flat ? q : ((q / RT_XCD_CHUNK) * 8u + xx) * RT_XCD_CHUNK + q % RT_XCD_CHUNK;
       c.next += n_win;
       bool lit = false;
       if (lane < n_win) {
