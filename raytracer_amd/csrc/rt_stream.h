@@ -661,8 +661,11 @@ __global__ __launch_bounds__(64, WAVES) void trace_closest_kernel(DevScene s, rt
 
 // The rays of the retrace list: closest hit in the reference's visiting order (ObjectGroup::intersect_iter,
 // group.rs:171-201), then the container walk, exactly as the single-kernel state machine settles them.
+#ifndef RT_RETRACE_WAVES
+#define RT_RETRACE_WAVES 4  // 128 registers, 59-140 spilled (162 and 3 waves without the bound): the walks are chains of dependent fetches, more of them in flight pay more than the spills cost (4K frame: retrace 0.97 -> 0.83 ms with 32 blocks per CU)
+#endif
 template <bool CAMERA, bool STATS>
-__global__ __launch_bounds__(64, 2) void retrace_kernel(DevScene s, rt_camera cam, DevOptions opt, Ws w, Batch b, uint32_t level,
+__global__ __launch_bounds__(64, RT_RETRACE_WAVES) void retrace_kernel(DevScene s, rt_camera cam, DevOptions opt, Ws w, Batch b, uint32_t level,
                                                         unsigned long long* stats, uint32_t* overflow_flag) {
   __shared__ uint2 lds_stack[RT_LDS_STACK * 64];
   uint2* lds = lds_stack + (threadIdx.x & 63u);

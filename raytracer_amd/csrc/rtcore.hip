@@ -1651,7 +1651,7 @@ struct TimedLaunch {  // records an event before and after one launch when the s
 #define RT_SHADE_BIG_SAMPLES (64u << 20)  // (rt_stream.h, RT_SHADE_SPAN_BIG)
 #endif
 #ifndef RT_RETRACE_BLOCKS_PER_CU
-#define RT_RETRACE_BLOCKS_PER_CU 16u  // few rays, long dependent walks: 4 -> 16 blocks per CU took 1.85 -> 1.35 ms off the 4K frame
+#define RT_RETRACE_BLOCKS_PER_CU 32u  // few rays, long dependent walks: 4 -> 16 blocks per CU took 1.85 -> 1.35 ms off the 4K frame (round 1); 16 -> 32 at 4 waves per SIMD 0.97 -> 0.83 ms (round 3)
 #endif
 template <bool CAMERA, bool STATS>
 int run_stream_batch(const rt_scene* sc, const stream::Ws& w, const rt_camera& cam, const DevOptions& dopt, const stream::Batch& b,
