@@ -5,6 +5,9 @@ use std::os::raw::{c_char, c_void};
 
 pub const RT_ABI_VERSION: u32 = 3;
 pub const RT_NONE: u32 = 0xFFFF_FFFF;
+pub const RT_TIMING_ALL: u32 = 1;
+pub const RT_TIMING_ONLY: u32 = 0x100;
+pub const RT_TIMING_CLASS_TRACE_SHADOW: u32 = 3;
 pub const RT_REF_NODE: u32 = 0;
 pub const RT_REF_PRIM: u32 = 1;
 pub const RT_REF_CSG: u32 = 2;
@@ -100,7 +103,7 @@ pub struct rt_options {
     pub shadow_intensity: u32,
     pub reference_order: u32, // 1: visit the BVH exactly as ObjectGroup::intersect_iter does (validation; slow)
     pub pipeline: u32,        // 0: streamed kernels (production); 1: single kernel
-    pub timing: u32,          // 1 (with stats): per-kernel HIP-event times instead of counters
+    pub timing: u32,          // RT_TIMING_ALL (with stats): per-kernel HIP-event times instead of counters; RT_TIMING_ONLY | class bits: those classes only
     pub n_devices: i32,       // rt_render: 0/1 = the current device, n > 1 = tiles over the first n devices, -1 = all
     pub progress: Option<unsafe extern "C" fn(pixels_done: u64, user: *mut c_void)>, // pixels finished since the last call
     pub user: *mut c_void,

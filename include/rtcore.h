@@ -178,6 +178,16 @@ typedef struct rt_camera {
  * `Integrator::use_shadow_intensity` (integrator.rs:19-32). */
 typedef void (*rt_progress_fn)(uint64_t pixels_done, void* user);
 
+/* rt_options.timing */
+#define RT_TIMING_ALL 1u
+#define RT_TIMING_ONLY 0x100u
+#define RT_TIMING_CLASS_TRACE_CLOSEST 0
+#define RT_TIMING_CLASS_RETRACE 1
+#define RT_TIMING_CLASS_SHADE 2
+#define RT_TIMING_CLASS_TRACE_SHADOW 3
+#define RT_TIMING_CLASS_COMBINE 4
+#define RT_TIMING_CLASS_OTHER 5
+
 typedef struct rt_options {
   uint32_t n_offsets;        /* 1..5 */
   double offsets[5];
@@ -192,7 +202,9 @@ typedef struct rt_options {
                                 Ignored when reference_order = 1 */
   uint32_t timing;           /* with stats != NULL and the streamed pipeline: launch the production kernels (no counters; the
                                 counter fields of rt_stats stay 0) with a HIP event before and after every launch, and report
-                                the time per kernel class in rt_stats.ms_* */
+                                the time per kernel class in rt_stats.ms_*.  RT_TIMING_ALL (1): every launch (~90 events per
+                                frame: ~0.3 ms of a 4K frame).  RT_TIMING_ONLY | (1 << RT_TIMING_CLASS_x) | ...: only the
+                                launches of the classes named (the other ms_* fields stay 0) */
   int32_t n_devices;         /* rt_render only (the reference's host is ONE process with a sequential frame loop,
                                 animation_renderer.rs:109-122, so this is how it reaches more than one GPU): 0 or 1 = the current
                                 HIP device; n > 1 = the frame's 8x8 tiles are dealt cyclically to the first n visible devices

@@ -587,6 +587,7 @@ struct rt_scene {
   mutable bool summary_pending = false;
   // rt_options.timing: HIP events around every launch of the streamed pipeline, by kernel class
   mutable bool timing_on = false;
+  mutable uint32_t timing_classes = ~0u;  // bit c: launches of class c are timed (RT_TIMING_ONLY)
   mutable std::vector<hipEvent_t> event_pool;
   mutable std::vector<int> timed_class;  // class of the i-th timed launch (events 2i, 2i+1 of the pool)
   ~rt_scene() {
@@ -1614,7 +1615,8 @@ struct TimedLaunch {  // records an event before and after one launch when the s
   const rt_scene* sc;
   hipStream_t st;
   bool on;
-  TimedLaunch(const rt_scene* scene, hipStream_t stream, int cls) : sc(scene), st(stream), on(scene->timing_on) {
+  TimedLaunch(const rt_scene* scene, hipStream_t stream, int cls)
+      : sc(scene), st(stream), on(scene->timing_on && ((scene->timing_classes >> cls) & 1u)) {
     if (!on) return;
     size_t i = sc->timed_class.size();
     while (sc->event_pool.size() < 2 * i + 2) {
@@ -1899,6 +1901,7 @@ int launch_render_once(const rt_scene* scene, const rt_camera* cam, const rt_opt
     } else {
       // rt_options.timing: the production kernels (no counters) with events around every launch
       scene->timing_on = stats && opt->timing;
+      scene->timing_classes = (opt->timing & RT_TIMING_ONLY) ? (opt->timing & 0xFFu) : ~0u;
       scene->timed_class.clear();
       rc = (stats && !opt->timing)
                ? launch_stream_render<true>(scene, cam, dopt, part, n_parts, tiles_x, n_owned, packed, d_out, stream, &progress)

@@ -701,6 +701,12 @@ def test_timing_mode_reports_kernel_classes():
     parts = sum(st[k] for k in ("ms_trace_closest", "ms_retrace", "ms_shade", "ms_trace_shadow", "ms_combine", "ms_other"))
     # (a batch this small runs level 0's shadow rays on the side stream, beside the other classes: include/rtcore.h, rt_stats)
     assert 0 < parts - st["ms_trace_shadow"] <= st["ms_kernel"] * 1.05 and 0 < st["ms_trace_shadow"] <= st["ms_kernel"] * 1.05
+    # RT_TIMING_ONLY | 1 << RT_TIMING_CLASS_TRACE_SHADOW (include/rtcore.h): events around that class's launches only
+    opt.timing = 0x100 | (1 << 3)
+    only = sc.render_device(cam, opt, out.data_ptr(), want_stats=True)
+    assert torch.equal(out, ref)
+    assert only["ms_trace_shadow"] > 0 and only["launches_trace_shadow"] == st["launches_trace_shadow"]
+    assert all(only[k] == 0 for k in ("ms_trace_closest", "ms_retrace", "ms_shade", "ms_combine", "ms_other")) and only["launches_trace_closest"] == 0
 
 
 # ---- CSG: the reference's truth tables (csg.rs:208-241) realised as geometry and replayed through the device ---------------

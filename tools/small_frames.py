@@ -6,7 +6,7 @@ import torch
 from raytracer_amd import renderer as R, distributed as D
 from raytracer_amd.harness import scene_yaml as Y
 import bench
-for wl, parts in (("dragons_4k_ss4_d5", 8), ("dragons_4k_ss4_d5", 4), ("dragons_4k_ss4_d5", 2), ("dragons_1080_ss4_d5", 1), ("dragons_1600_ss2_d5", 1), ("dragons_800_ss2_d5", 1),
+for wl, parts in (("dragons_4k_ss4_d5", 1), ("dragons_4k_ss4_d5", 8), ("dragons_4k_ss4_d5", 4), ("dragons_4k_ss4_d5", 2), ("dragons_1080_ss4_d5", 1), ("dragons_1600_ss2_d5", 1), ("dragons_800_ss2_d5", 1),
                   ("dragon_800_ss2_d5", 1), ("csg_lens_800_ss2_d8", 1), ("refractions_800_ss2_d8", 1), ("readme_800_ss2_d5", 1)):
     path, w, h, ss, depth = bench.WORKLOADS[wl]
     rs = Y.load_scene(os.path.join(bench.ROOT, path), width=w, height=h, depth=depth, supersampling_level=ss)
