@@ -686,6 +686,37 @@ def test_scenes_reuse_device_blocks_of_destroyed_scenes():
             L.rt_release_cached_memory()
 
 
+def test_work_hand_out_at_every_launch_size():
+    """The trace kernels hand rays out in three ways (rt_stream.h, xcd_cursor): no counters when a launch has at most one
+    group of rays per wavefront (groups of 8..64), and otherwise a first range per wavefront that is its own by position with
+    counters for what lies behind.  Ray counts on both sides of every switch — and ragged ones — through rt_trace_rays: every
+    ray's colour equals the reference-order kernel's, which takes none of these paths (a ray that was never handed out
+    would stay black; most of these rays are not)."""
+    torch = _torch()
+    rs = Y.load_scene(scene_path("images", "chapters/reflections"), width=64, height=64, depth=3, supersampling_level=1)
+    flat = rs.builder.flatten()
+    sc = R.DeviceScene(flat)
+    opt = S.make_options(1, 3, True)
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    grids = sorted({cus * 4 * w for w in (3, 4)})  # wavefronts of the closest-hit / shadow kernels
+    sizes = {1, 7, 8, 9, 63, 64, 65, 1000}
+    for g in grids:
+        for lanes in (8, 16, 32, 64):
+            sizes |= {g * lanes - 1, g * lanes, g * lanes + 1}
+        sizes |= {g * 64 + 63, g * 64 + 64 * 7 + 5, g * 256 + 3, g * 4 * 256 + 129}
+    rng = np.random.default_rng(11)
+    n_max = max(sizes)
+    origins = rng.uniform(-4, 4, (n_max, 3))
+    origins[:, 1] = np.abs(origins[:, 1]) + 0.5
+    dirs = rng.normal(size=(n_max, 3))
+    dirs /= np.linalg.norm(dirs, axis=1, keepdims=True)
+    ref = sc.trace_rays(_ref_order(opt), origins, dirs)
+    assert np.isfinite(ref).all() and (ref.sum(axis=1) > 0).mean() > 0.5
+    for n in sorted(sizes):
+        got = sc.trace_rays(opt, origins[:n], dirs[:n])
+        assert np.array_equal(got, ref[:n]), n
+
+
 def test_timing_mode_reports_kernel_classes():
     torch = _torch()
     rs = Y.load_scene(scene_path("images", "general/cover"), width=256, height=256, depth=5, supersampling_level=2)
