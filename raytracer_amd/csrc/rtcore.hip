@@ -1640,8 +1640,11 @@ struct TimedLaunch {  // records an event before and after one launch when the s
 #ifndef RT_SHADOW_ON_SIDE_STREAM
 #define RT_SHADOW_ON_SIDE_STREAM 1  // 0: every kernel of the pipeline on the caller's stream, one after the other
 #endif
-#ifndef RT_SHADOW_SIDE_SAMPLES
-#define RT_SHADOW_SIDE_SAMPLES (64u << 20)
+#ifndef RT_SHADOW_SIDE_MID
+#define RT_SHADOW_SIDE_MID (16u << 20)
+#endif
+#ifndef RT_SHADOW_SIDE_BIG
+#define RT_SHADOW_SIDE_BIG (64u << 20)
 #endif
 #ifndef RT_SHADOW_SIDE_LEVELS
 #define RT_SHADOW_SIDE_LEVELS 1u  // levels 0 .. this - 1: a shadow launch per level on the side stream; the rest: one launch at the end
@@ -1662,25 +1665,37 @@ int run_stream_batch(const rt_scene* sc, const stream::Ws& w, const rt_camera& c
   const uint32_t wide_grid = (uint32_t)sc->n_cus * 8u, no_walk_grid = (uint32_t)sc->n_cus * 4u * RT_CLOSEST_WAVES_NO_WALK;
   uint32_t need = (b.n_samples + 255u) / 256u;
   const uint32_t first_grid = std::max(1u, std::min(wide_grid, need));
-  // The shadow rays of level 0 (most of them) can run on the scene's side stream, beside the deeper levels' trace / shade
-  // kernels, which hold few rays and pay a latency floor per launch (a dependent chain of ~150 node steps): measured -8 %
-  // on an 800x800 frame (3.50 -> 3.23 ms), but +1 % on the 4K frame, whose every kernel fills the GPU by itself and only
-  // loses cache locality to a neighbour.  So: only for batches below RT_SHADOW_SIDE_SAMPLES samples.
-  static const uint64_t side_below = [] {
+  // The shadow rays of the first levels run on the scene's side stream, level by level, beside the next levels' trace / shade
+  // kernels; the shadow rays of the other levels are one launch after the last level.  How many levels (k):
+  //  * small batches: k = 1 (round 2: an 800x800 frame 3.50 -> 3.23 ms; k = 2 is better for dragons.yml at 800x800 but worse for
+  //    the one-dragon room, the CSG lens and refractions.yml, whose levels are all of one size);
+  //  * from RT_SHADOW_SIDE_MID samples (16 Mi): k = 2 (1080p ss 4 9.07 -> 8.89 ms, an eighth of the 4K frame 4.89 -> 4.79);
+  //  * from RT_SHADOW_SIDE_BIG samples (64 Mi): k = 3 (the 4K frame 28.2 -> 27.4 ms, half of it 15.4 -> 14.9).
+  // Until the end of round 3 big batches used no side stream at all (+1 % then: every kernel of the 4K frame fills the GPU by
+  // itself): that was the work hand-out's doing — a launch beside another doubled the traffic on the same eight counters,
+  // and every returning atomic is a round trip the whole wavefront waits for (rt_stream.h, RT_XCD_MIN_GRAB).
+  // RT_SHADOW_SIDE_LEVELS in the environment fixes k for every size (development), RT_SHADOW_SIDE_SAMPLES bounds the batches
+  // that use the side stream at all.
+  const uint64_t side_below = [] {  // (read per batch: bench.py switches it between steps to time every kernel alone)
     const char* e = std::getenv("RT_SHADOW_SIDE_SAMPLES");
-    return e ? std::strtoull(e, nullptr, 10) : (uint64_t)RT_SHADOW_SIDE_SAMPLES;
+    return e ? std::strtoull(e, nullptr, 10) : ~0ull;
   }();
   const bool use_side = RT_SHADOW_ON_SIDE_STREAM && allow_side && dopt.max_depth > 0 && b.n_samples < side_below;
-  static const uint32_t side_levels = [] {
+  const uint32_t side_levels_env = [] {
     const char* e = std::getenv("RT_SHADOW_SIDE_LEVELS");
-    return e ? (uint32_t)std::strtoul(e, nullptr, 10) : (uint32_t)RT_SHADOW_SIDE_LEVELS;
+    return e ? (uint32_t)std::strtoul(e, nullptr, 10) : 0u;
   }();
+  const uint32_t side_levels = side_levels_env ? side_levels_env
+                                               : (b.n_samples >= RT_SHADOW_SIDE_BIG ? 3u : (b.n_samples >= RT_SHADOW_SIDE_MID ? 2u : (uint32_t)RT_SHADOW_SIDE_LEVELS));
   hipStream_t side = use_side ? sc->side_stream : st;
   auto launch_shadow = [&](uint32_t first, uint32_t last, hipStream_t on) {
+    // (a side-stream launch that leaves 1/8, 1/4 or 1/2 of the wavefront slots to the main stream's kernels: the 4K frame 27.1 ->
+    // 27.8 / 28.4 / 31.8 ms: what the overlap buys is the filling of each other's tails, not two kernels side by side)
+    const uint32_t grid = trace_grid;
     if (STATS || sc->has_csg)
-      hipLaunchKernelGGL((stream::trace_shadow_kernel<STATS, true>), dim3(trace_grid), dim3(64), 0, on, sc->dev, w, first, last, sc->d_stats, sc->d_overflow);
+      hipLaunchKernelGGL((stream::trace_shadow_kernel<STATS, true>), dim3(grid), dim3(64), 0, on, sc->dev, w, first, last, sc->d_stats, sc->d_overflow);
     else
-      hipLaunchKernelGGL((stream::trace_shadow_kernel<false, false>), dim3(trace_grid), dim3(64), 0, on, sc->dev, w, first, last, sc->d_stats, sc->d_overflow);
+      hipLaunchKernelGGL((stream::trace_shadow_kernel<false, false>), dim3(grid), dim3(64), 0, on, sc->dev, w, first, last, sc->d_stats, sc->d_overflow);
   };
   HIP_TRY(hipMemsetAsync(w.ctrl, 0, sizeof(stream::Ctrl), st));
   HIP_TRY(hipMemsetAsync(w.sample_flag, 0, b.n_samples, st));

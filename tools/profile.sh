@@ -5,6 +5,10 @@ tag=${1:-r01}
 out=$PWD/gpurun_out/prof_$tag
 mkdir -p $out
 export TMPDIR=/tmp
+# every kernel alone on the GPU (no side stream): per-kernel durations and counters are then the kernel's own, and agree with
+# bench.py's roofline.kernel_ms (which is measured in steps run the same way); the production schedule overlaps the first levels'
+# shadow launches with the next levels' kernels
+export RT_SHADOW_SIDE_SAMPLES=0
 run() { name=$1; shift; timeout -s KILL 240 rocprofv3 "$@" --output-format csv -d $out/$name -o $name -- python3 tools/prof_driver.py dragons_4k_ss4_d5 2 > $out/$name.log 2>&1 || { echo "pass $name failed"; tail -5 $out/$name.log; exit 1; }; echo "pass $name ok"; }
 timeout -s KILL 400 rocprofv3 --kernel-trace --stats --output-format csv -d $out/bench -o bench -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-one-shot > $out/bench.log 2>&1 || { echo bench trace failed; tail -5 $out/bench.log; exit 1; }
 echo "pass bench ok"
