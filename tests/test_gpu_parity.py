@@ -717,6 +717,38 @@ def test_work_hand_out_at_every_launch_size():
         assert np.array_equal(got, ref[:n]), n
 
 
+def test_shadow_launch_schedule_does_not_change_pixels():
+    """The shadow rays of the first k levels run level by level on the scene's side stream, the rest in one launch after the last
+    level; k depends on the batch size (rtcore.hip, run_stream_batch).  RT_SHADOW_SIDE_LEVELS / RT_SHADOW_SIDE_SAMPLES (read per
+    batch) force every schedule on one small frame: no side stream at all, k = 1, 2, 3 and more levels than the frame has."""
+    torch = _torch()
+    rs = Y.load_scene(scene_path("images", "chapters/refractions"), width=200, height=160, depth=4, supersampling_level=2)
+    flat, cam, opt = rs.builder.flatten(), rs.camera, rs.options()
+    sc = R.DeviceScene(flat)
+    out = torch.zeros((cam.height, cam.width, 3), dtype=torch.float64, device="cuda")
+    keep = {k: os.environ.get(k) for k in ("RT_SHADOW_SIDE_LEVELS", "RT_SHADOW_SIDE_SAMPLES")}
+    try:
+        os.environ["RT_SHADOW_SIDE_SAMPLES"] = "0"
+        sc.render_device(cam, opt, out.data_ptr())
+        torch.cuda.synchronize()
+        ref = out.clone()
+        del os.environ["RT_SHADOW_SIDE_SAMPLES"]
+        for k in (1, 2, 3, 9):
+            os.environ["RT_SHADOW_SIDE_LEVELS"] = str(k)
+            out.zero_()
+            sc.render_device(cam, opt, out.data_ptr())
+            torch.cuda.synchronize()
+            assert torch.equal(out, ref), k
+    finally:
+        for k, v in keep.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    want, _ = O.render(flat, cam, opt)
+    assert float(np.abs(ref.cpu().numpy() - want).max()) < F64_TOL
+
+
 def test_timing_mode_reports_kernel_classes():
     torch = _torch()
     rs = Y.load_scene(scene_path("images", "general/cover"), width=256, height=256, depth=5, supersampling_level=2)
