@@ -251,8 +251,12 @@ typedef struct rt_stats {
   double ms_upload, ms_kernel, ms_download;
   double ms_trace_closest, ms_retrace, ms_shade, ms_trace_shadow, ms_combine, ms_other; /* rt_options.timing: GPU time of the
                               streamed pipeline's launches by kernel class, HIP events around each launch, summed over the frame.
-                              Small batches run level 0's shadow rays on a second stream beside the deeper levels' kernels:
-                              ms_trace_shadow then overlaps the other classes, and the sum of the classes can exceed ms_kernel */
+                              The shadow rays of the first 1-3 levels run on a second stream of the scene's own beside the next
+                              levels' kernels (ordered against the caller's stream by events; nothing of a frame is still running
+                              when the work this call enqueued on `hip_stream` has completed): an event pair around such a launch
+                              also times its wait for wavefront slots, the classes' spans overlap, and their sum can exceed
+                              ms_kernel.  RT_SHADOW_SIDE_SAMPLES=0 in the environment (read per batch) keeps every kernel on
+                              `hip_stream`, one after the other: a class's time is then its kernels' own */
 } rt_stats;
 
 /* ---- library ------------------------------------------------------------------------------ */
