@@ -565,7 +565,7 @@ struct rt_scene {
   uint32_t n_lights = 0;
   bool general_csg = false;  // a CSG object of the scene is beyond what the production kernels evaluate (more than RT_CSG_LIST_MAX
                              // intersections in the worst case, nesting beyond RT_CSG_NEST_MAX, a CSG object inside a group that
-                             // is a CSG operand): every render of the scene runs the reference-order kernel with the general
+                             // is a CSG operand; or a CSG operand that is not a closed surface, is_solid): every render of the scene runs the reference-order kernel with the general
                              // evaluation (rt_shapes.h csg_survivors_general) — several times slower, never refused
   bool has_csg = false;  // the scene holds CSG objects: the trace kernels built with their evaluation are launched
   bool has_walks = true; // some primitive's closest hit is followed by the container walk (DevScene::prim_flags)
@@ -1211,6 +1211,28 @@ uint32_t max_roots(const rt_scene_desc* d, uint32_t prim) {
   }
 }
 
+// A shape that a line crosses an even number of times.  CsgObject::filter_intersections (csg.rs:87-110) takes "inside the left
+// / right operand" from the PARITY of the operand's intersections so far, and a CSG object's bounding box is put together from
+// its operands' boxes (csg.rs:131-143: the left one's for a difference, the boxes' intersection for an intersection).  With an
+// operand that is not a closed surface — a plane, a triangle, a cylinder or cone without caps — the parity says "inside" where
+// the ray is far outside the operand, so the object reports intersections OUTSIDE its own box (found by tools/fuzz_csg.py,
+// seed 6384: a cone without caps minus a group).  The reference then still finds them whenever the LINE of the ray crosses the
+// enclosing group's box, also behind the origin (BoundingBox::intersection_time, bounding_box.rs:192-225, has no "behind"
+// test), and which of them it finds depends on its visiting order (group.rs:182 skips by entry time).  The production
+// traversal relies on geometry lying inside its boxes (it passes over boxes behind the origin and visits nearest first): a
+// scene with such an operand is rendered by the reference-order kernels (rt_scene::general_csg), which walk exactly as the
+// reference does.
+bool is_solid(const rt_scene_desc* d, uint32_t prim) {
+  switch (d->prim_shape[prim]) {
+    case RT_SHAPE_SPHERE:
+    case RT_SHAPE_CUBE:
+    case RT_SHAPE_BBOX: return true;
+    case RT_SHAPE_CYLINDER:
+    case RT_SHAPE_CONE: return d->quadric_closed[d->prim_geom[prim]] != 0;
+    default: return false;
+  }
+}
+
 // The object graph reachable from the root must be a tree (the reference's objects own their children): no reference
 // back to an ancestor — the layout passes below recurse over it —, nothing referenced twice.  Also checked here, because
 // they need the same walk: csg_depth is the real CSG nesting; what the device's CSG evaluation is bounded by
@@ -1244,7 +1266,10 @@ int check_graph(const rt_scene_desc* d, bool* general) {
     }
     uint32_t ref = child(f.v, f.next++), kind = ref >> RT_REF_KIND_SHIFT, idx = ref & RT_REF_INDEX_MASK;
     if (kind == RT_REF_PRIM) {
-      if (f.in_csg) f.roots += max_roots(d, idx);
+      if (f.in_csg) {
+        f.roots += max_roots(d, idx);
+        if (!is_solid(d, idx)) *general = true;
+      }
       continue;
     }
     if (kind == RT_REF_MESH) {

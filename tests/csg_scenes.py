@@ -52,9 +52,11 @@ def csg_in_group_in_csg():
     return sb
 
 
-def random_nested(seed, depth=4):
+def random_nested(seed, depth=4, solid_only=False, csg=True, planes=False):
     """A seeded random tree of CSG objects, groups and primitives (spheres, cubes, cylinders, cones; a fifth of them glass) below one
-    outermost CSG object, over a checkered floor: whatever nesting comes out — bounded or general evaluation."""
+    outermost CSG object, over a checkered floor: whatever nesting comes out — bounded or general evaluation.
+    solid_only: every cylinder / cone has its caps (CSG objects of closed surfaces only: the production kernels render them);
+    csg = False: groups only; planes: a tenth of the primitives are planes."""
     import numpy as np
     rng = np.random.default_rng(1000 + seed)
     sb = S.SceneBuilder()
@@ -65,20 +67,25 @@ def random_nested(seed, depth=4):
 
     def primitive():
         kind = [N.SPHERE, N.CUBE, N.CYLINDER, N.CONE][int(rng.integers(0, 4))]
+        if planes and rng.random() < 0.1:
+            kind = N.PLANE
         mat = S.Material.glass() if rng.random() < 0.2 else S.Material.with_color(tuple(float(v) for v in rng.uniform(0.1, 1., 3)))
-        kw = dict(y_min=-1., y_max=1., closed=bool(rng.random() < 0.5)) if kind in (N.CYLINDER, N.CONE) else {}
+        kw = dict(y_min=-1., y_max=1., closed=bool(solid_only or rng.random() < 0.5)) if kind in (N.CYLINDER, N.CONE) else {}
         return sb.primitive(kind, mat, transform(), **kw)
 
     def obj(d):
         r = rng.random()
         if d <= 0 or r < 0.3:
             return primitive()
-        if r < 0.65:
+        if r < 0.65 and csg:
             op = [N.CSG_UNION, N.CSG_INTERSECTION, N.CSG_DIFFERENCE][int(rng.integers(0, 3))]
             return sb.csg(op, obj(d - 1), obj(d - 1))
         return sb.group([obj(d - 1) for _ in range(int(rng.integers(1, 4)))])
 
-    sb.add_object(sb.csg(N.CSG_UNION if seed % 3 else N.CSG_DIFFERENCE, obj(depth), obj(depth)))
+    if csg:
+        sb.add_object(sb.csg(N.CSG_UNION if seed % 3 else N.CSG_DIFFERENCE, obj(depth), obj(depth)))
+    else:
+        sb.add_object(sb.group([obj(depth), obj(depth)]))
     sb.add_object(sb.primitive(N.PLANE, S.Material(S.Pattern(N.P_CHECKERS, (1., 1., 1.), (0.3, 0.3, 0.3))), _tr(0., -2.5, 0.)))
     sb.add_light((-4., 6., -6.), (1., 1., 1.))
     return sb

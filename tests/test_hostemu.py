@@ -59,7 +59,7 @@ for name, make in csg_scenes.GENERAL:
         if not d < 1e-9 or not (want.sum(axis=2) > 0).sum() > 50:
             sys.exit(5)
 cam = S.make_camera(28, 21, 1.0, S.view_transformation((1.5, 1.5, -6.), (0., 0., 0.), (0., 1., 0.)))
-for seed in range(24):  # seeded random trees of CSG objects, groups and primitives
+for seed in list(range(24)) + [6384]:  # seeded random trees of CSG objects, groups and primitives (6384: intersections outside the object's box)
     flat = csg_scenes.random_nested(seed).flatten(build_bvh=bool(seed % 2))
     opt = S.make_options(1, 3, True)
     want, _ = O.render(flat, cam, opt)
