@@ -257,3 +257,69 @@ def test_builds_for_two_live_scenes():
             alive.pop(0).close()
     for s in alive:
         s.close()
+
+
+@pytest.mark.parametrize("seed", list(range(0, 28)))
+def test_device_build_on_awkward_triangle_groups(seed):
+    """tests/mesh_cases.py (kind = seed % 7): the device builds the tree the host builds — same triangles in the same order,
+    same groups with the same boxes, same visit ranks, same pixels.  A tree whose SA-guided 4-wide fold (the host's) needs
+    more stack entries than the device holds is refused loudly; the device's own fold of the same tree (two
+    levels per wide node) may need fewer and render it: then its pixels are checked against its own reference-order walk.
+    tools/fuzz_mesh.py runs thousands of these."""
+    import torch
+    from mesh_cases import triangles
+    from raytracer_amd.harness import scene as S
+
+    def build(device):
+        sb = S.SceneBuilder()
+        mat = S.Material.with_color((0.2, 0.7, 0.3))
+        sb.add_object(sb.group([sb.primitive(N.TRIANGLE, mat, tri=[float(v) for v in t]) for t in triangles(seed)]))
+        sb.add_light((-10., 10., -10.), (1., 1., 1.))
+        if device:
+            assert sb.extract_meshes(64) == 1
+        return sb
+
+    fh, fd = build(False).flatten(build_bvh=True), build(True).flatten(build_bvh=True)
+    try:
+        sh = R.DeviceScene(fh)
+    except Exception as e:  # noqa: BLE001
+        assert "traversal stack" in str(e)
+        try:
+            sd = R.DeviceScene(fd)
+        except Exception as e2:  # noqa: BLE001
+            assert "traversal stack" in str(e2)
+            return
+        assert (check_wide_nodes(sd) == 1).all()
+        cam = S.make_camera(48, 48, 1.2, S.view_transformation((0, 2, -12), (0, 0, 0), (0, 1, 0)))
+        out = []
+        for ro in (0, 1):
+            opt = S.make_options(1, 2)
+            opt.reference_order = ro
+            d = torch.empty((48, 48, 3), dtype=torch.float64, device="cuda")
+            sd.render_device(cam, opt, d.data_ptr(), 0)
+            torch.cuda.synchronize()
+            out.append(d.cpu().numpy())
+        assert np.array_equal(out[0], out[1])
+        sd.close()
+        return
+    sd = R.DeviceScene(fd)
+    th, td = table(sh, TRI_ISECT, np.uint64).reshape(-1, 10), table(sd, TRI_ISECT, np.uint64).reshape(-1, 10)
+    assert th.shape == td.shape and np.array_equal(th[:, :9], td[:, :9])
+    prim_map = {}
+    compare_trees(reference_tree(sh), reference_tree(sd), prim_map)
+    rh, rd = table(sh, PRIM_RANK, np.uint32), table(sd, PRIM_RANK, np.uint32)
+    keys = np.array(sorted(prim_map), dtype=np.int64)
+    vals = np.array([prim_map[int(k)] for k in keys], dtype=np.int64)
+    assert len(keys) == len(rh) == len(rd) and np.array_equal(rh[keys], rd[vals])
+    assert (check_wide_nodes(sd) == 1).all()
+    cam = S.make_camera(48, 48, 1.2, S.view_transformation((0, 2, -12), (0, 0, 0), (0, 1, 0)))
+    opt = S.make_options(1, 2)
+    out = []
+    for sc in (sh, sd):
+        d = torch.empty((48, 48, 3), dtype=torch.float64, device="cuda")
+        sc.render_device(cam, opt, d.data_ptr(), 0)
+        torch.cuda.synchronize()
+        out.append(d.cpu().numpy())
+    assert np.array_equal(out[0], out[1])
+    sh.close()
+    sd.close()
