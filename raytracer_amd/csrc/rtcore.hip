@@ -565,7 +565,8 @@ struct rt_scene {
   uint32_t n_lights = 0;
   bool general_csg = false;  // a CSG object of the scene is beyond what the production kernels evaluate (more than RT_CSG_LIST_MAX
                              // intersections in the worst case, nesting beyond RT_CSG_NEST_MAX, a CSG object inside a group that
-                             // is a CSG operand; or a CSG operand that is not a closed surface, is_solid): every render of the scene runs the reference-order kernel with the general
+                             // is a CSG operand; or a CSG operand that is not a closed surface, is_solid) — or the scene holds a
+                             // primitive that sticks out of its own bounding box (a cone's cap at |y| < 1, validate) —: every render of the scene runs the reference-order kernel with the general
                              // evaluation (rt_shapes.h csg_survivors_general) — several times slower, never refused
   bool has_csg = false;  // the scene holds CSG objects: the trace kernels built with their evaluation are launched
   bool has_walks = true; // some primitive's closest hit is followed by the container walk (DevScene::prim_flags)
@@ -1358,6 +1359,18 @@ int validate(const rt_scene_desc* d, bool* general) {
       total += m->n;
     }
     if (total + d->n_prims > RT_REF_INDEX_MASK) return fail(RT_ERR_UNSUPPORTED, "too many primitives");
+  }
+  // A cone's cap test is x^2 + z^2 <= |y| (cone.rs:106-112: the radius, not its square), so a cap at |y| < 1 is a disk of
+  // radius sqrt|y| > |y|, while the cone's bounding box takes max(|y_min|, |y_max|) for the radius (cone.rs:96-104): such a cap
+  // sticks out of the cone's box, and out of every group's box above it.  As with the CSG operands of is_solid: the reference
+  // finds those intersections whenever the ray's LINE crosses the group's box and its visiting order lets it, which the
+  // production traversal cannot reproduce (found by tools/fuzz_scenes.py: 7 of 1500 random scenes differed in 1-3 pixels,
+  // every one of them with such a cone).  The scene takes the reference-order kernels.  (The reference's own cones — min -1
+  // max 0, min 0 max 1 — are not of this kind.)
+  for (uint32_t i = 0; i < d->n_prims; i++) {
+    if (d->prim_shape[i] != RT_SHAPE_CONE || !d->quadric_closed[d->prim_geom[i]]) continue;
+    const double a = std::fabs(d->quadric_y_min[d->prim_geom[i]]), b = std::fabs(d->quadric_y_max[d->prim_geom[i]]), r = std::max(a, b);
+    if (std::sqrt(a) > r || std::sqrt(b) > r) *general = true;
   }
   for (uint32_t i = 0; i < d->n_csgs; i++) {
     if ((d->csg_left[i] >> RT_REF_KIND_SHIFT) == RT_REF_MESH || (d->csg_right[i] >> RT_REF_KIND_SHIFT) == RT_REF_MESH)

@@ -1,0 +1,86 @@
+"""Seeded random scenes for parity fuzzing (tools/fuzz_scenes.py, tests/test_gpu_parity.py): primitives of every analytic
+shape and small triangle fans in nested groups, materials with every pattern kind (transformed), mirrors, glass of several
+refractive indices — overlapping, so that rays start and end inside containers —, partly transparent shadow casters, one to
+six lights, a floor; camera, supersampling level, depth and the shadow-intensity option vary with the seed."""
+import numpy as np
+
+from raytracer_amd import _native as N
+from raytracer_amd.harness import scene as S
+
+
+def random_scene(seed):
+    rng = np.random.default_rng(50_000 + seed)
+    sb = S.SceneBuilder()
+
+    def matrix(scale=(0.3, 1.0), spread=1.8):
+        t = [S.Transformation.scaling(*[float(v) for v in rng.uniform(*scale, 3)])]
+        if rng.random() < 0.6:
+            t.append(S.Transformation.rotation(int(rng.integers(0, 3)), float(rng.uniform(-3.1, 3.1))))
+        t.append(S.Transformation.translation(*[float(v) for v in rng.uniform(-spread, spread, 3)]))
+        return S.matrix_from_transformations(t)
+
+    def colour():
+        return tuple(float(v) for v in rng.uniform(0.05, 1., 3))
+
+    def material():
+        r = rng.random()
+        if r < 0.22:  # glass of some index; index 1.0 exactly now and then (no bending: the walk-free kernels if all are)
+            m = S.Material.glass()
+            m.refractive_index = float(rng.choice([1.0, 1.1, 1.33, 1.5, 2.4]))
+            m.transparency = float(rng.choice([0.9, 0.5, 1.0]))
+            m.reflectivity = float(rng.choice([0.9, 0.0, 0.3]))
+            return m
+        kind = int(rng.choice([N.P_CONST, N.P_CONST, N.P_STRIPE, N.P_GRADIENT, N.P_RING, N.P_CHECKERS]))
+        pat = S.Pattern(kind, colour(), colour(), matrix((0.1, 0.6), 0.5) if kind != N.P_CONST and rng.random() < 0.7 else S.IDENTITY)
+        m = S.Material(pat, ambient=float(rng.uniform(0., 0.3)), diffuse=float(rng.uniform(0.3, 1.)),
+                       specular=float(rng.choice([0., 0.3, 0.9])), shininess=float(rng.choice([10., 50., 200., 300.])))
+        if r < 0.4:
+            m.reflectivity = float(rng.uniform(0.1, 1.))
+        if r > 0.9:
+            m.transparency = float(rng.uniform(0.1, 0.6))  # a coloured, partly transparent shadow caster
+        return m
+
+    def primitive():
+        kind = int(rng.choice([N.SPHERE, N.SPHERE, N.CUBE, N.CYLINDER, N.CONE, N.PLANE if rng.random() < 0.15 else N.SPHERE]))
+        kw = {}
+        if kind in (N.CYLINDER, N.CONE):
+            lo = float(rng.uniform(-1.5, 0.))
+            kw = dict(y_min=lo, y_max=lo + float(rng.uniform(0.3, 2.)), closed=bool(rng.random() < 0.6))
+            if kind == N.CONE and kw["closed"] and rng.random() < 0.85:
+                # caps at |y| >= 1 or at the apex: a cap at 0 < |y| < 1 sticks out of the cone's box (cone.rs:106-112 compares
+                # x^2 + z^2 with |y|, not y^2), and a scene with such a cone takes the reference-order kernels
+                lo, hi = [(-1., 0.), (0., 1.), (-1., 1.), (-2., -1.), (1., 2.5), (-1.5, 1.)][int(rng.integers(0, 6))]
+                kw.update(y_min=lo, y_max=hi)
+        return sb.primitive(kind, material(), matrix(), **kw)
+
+    def fan():
+        c = rng.uniform(-1.5, 1.5, 3)
+        mat = material()
+        tris = []
+        for _ in range(int(rng.integers(1, 7))):
+            pts = (c[None, :] + rng.uniform(-0.6, 0.6, (3, 3))).reshape(-1)
+            tris.append(sb.primitive(N.TRIANGLE, mat, tri=[float(v) for v in pts]))
+        return sb.group(tris)
+
+    def obj(d):
+        r = rng.random()
+        if d <= 0 or r < 0.45:
+            return primitive()
+        if r < 0.6:
+            return fan()
+        return sb.group([obj(d - 1) for _ in range(int(rng.integers(1, 5)))])
+
+    for _ in range(int(rng.integers(2, 7))):
+        sb.add_object(obj(3))
+    sb.add_object(sb.primitive(N.PLANE, S.Material(S.Pattern(N.P_CHECKERS, (1., 1., 1.), (0.25, 0.25, 0.25)), reflectivity=float(rng.choice([0., 0.3]))),
+                               S.matrix_from_transformations([S.Transformation.translation(0., -2.6, 0.)])))
+    for _ in range(int(rng.integers(1, 7))):
+        p = rng.uniform(-8, 8, 3)
+        p[1] = abs(p[1]) + 2.
+        sb.add_light(tuple(float(v) for v in p), tuple(float(v) for v in rng.uniform(0.1, 0.7, 3)))
+    eye = rng.uniform(-1, 1, 3) * np.array([5., 2., 1.]) + np.array([0., 1.5, -7.])
+    if rng.random() < 0.15:
+        eye = rng.uniform(-0.8, 0.8, 3)  # inside the scene (possibly inside a glass object)
+    cam = S.make_camera(40, 30, float(rng.uniform(0.6, 1.4)), S.view_transformation(tuple(float(v) for v in eye), (0., 0., 0.), (0., 1., 0.)))
+    opt = S.make_options(int(rng.integers(0, 3)), int(rng.integers(0, 7)), bool(rng.random() < 0.8))
+    return sb, cam, opt, bool(rng.random() < 0.7)

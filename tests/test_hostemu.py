@@ -68,6 +68,16 @@ for seed in list(range(24)) + [6384]:  # seeded random trees of CSG objects, gro
     if not d < 1e-9:
         print("random_nested", seed, d, flush=True)
         sys.exit(6)
+from random_scenes import random_scene
+for seed in range(3000, 3040):
+    sb, cam, opt, bvh = random_scene(seed)
+    flat = sb.flatten(build_bvh=bvh)
+    want, _ = O.render(flat, cam, opt)
+    got, _ = R.render(flat, cam, opt)
+    d = float(np.abs(got - want).max())
+    if not d < 1e-9:
+        print("random_scene", seed, d, flush=True)
+        sys.exit(7)
 print("OK")
 """
 
