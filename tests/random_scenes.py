@@ -8,11 +8,17 @@ from raytracer_amd import _native as N
 from raytracer_amd.harness import scene as S
 
 
-def random_scene(seed):
-    rng = np.random.default_rng(50_000 + seed)
+def random_scene(seed, aligned=False):
+    """aligned: scales of 1/2, 1, 2, no rotations, positions and lights on a half-unit grid, the camera on an axis looking along
+    it, an odd image size: rays with components that are exactly 0 (1 / d infinite: the slab test's 0 x inf cases), surfaces that
+    coincide, rays that graze faces and edges."""
+    rng = np.random.default_rng((90_000 if aligned else 50_000) + seed)
     sb = S.SceneBuilder()
 
     def matrix(scale=(0.3, 1.0), spread=1.8):
+        if aligned:
+            return S.matrix_from_transformations([S.Transformation.scaling(*[float(v) for v in rng.choice([0.5, 1., 2.], 3)]),
+                                                  S.Transformation.translation(*[float(v) for v in rng.integers(-4, 5, 3) * 0.5])])
         t = [S.Transformation.scaling(*[float(v) for v in rng.uniform(*scale, 3)])]
         if rng.random() < 0.6:
             t.append(S.Transformation.rotation(int(rng.integers(0, 3)), float(rng.uniform(-3.1, 3.1))))
@@ -77,10 +83,17 @@ def random_scene(seed):
     for _ in range(int(rng.integers(1, 7))):
         p = rng.uniform(-8, 8, 3)
         p[1] = abs(p[1]) + 2.
+        if aligned:
+            p = np.round(p * 2.) / 2.
         sb.add_light(tuple(float(v) for v in p), tuple(float(v) for v in rng.uniform(0.1, 0.7, 3)))
     eye = rng.uniform(-1, 1, 3) * np.array([5., 2., 1.]) + np.array([0., 1.5, -7.])
     if rng.random() < 0.15:
         eye = rng.uniform(-0.8, 0.8, 3)  # inside the scene (possibly inside a glass object)
+    if aligned:
+        h = float(rng.integers(-2, 5)) * 0.5
+        cam = S.make_camera(41, 31, float(np.pi / 2.), S.view_transformation((0., h, -6.), (0., h, 0.), (0., 1., 0.)))
+        opt = S.make_options(int(rng.integers(0, 3)), int(rng.integers(0, 7)), bool(rng.random() < 0.8))
+        return sb, cam, opt, bool(rng.random() < 0.7)
     cam = S.make_camera(40, 30, float(rng.uniform(0.6, 1.4)), S.view_transformation(tuple(float(v) for v in eye), (0., 0., 0.), (0., 1., 0.)))
     opt = S.make_options(int(rng.integers(0, 3)), int(rng.integers(0, 7)), bool(rng.random() < 0.8))
     return sb, cam, opt, bool(rng.random() < 0.7)
