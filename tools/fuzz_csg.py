@@ -18,6 +18,8 @@ cam = S.make_camera(40, 30, 1.0, S.view_transformation((1.5, 1.5, -6.), (0., 0.,
 bad = 0
 refused = 0
 for seed in range(first, first + n):
+    if (seed - first) % 2000 == 0:
+        print("... seed", seed, flush=True)
     try:
         flat = csg_scenes.random_nested(seed, **KW).flatten(build_bvh=bool(seed % 2))
     except Exception as e:

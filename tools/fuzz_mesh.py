@@ -30,6 +30,8 @@ cam = S.make_camera(48, 48, 1.2, S.view_transformation((0, 2, -12), (0, 0, 0), (
 opt = S.make_options(1, 2)
 bad = refused = 0
 for seed in range(first, first + n_seeds):
+    if (seed - first) % 2000 == 0:
+        print("... seed", seed, flush=True)
     try:
         fh, fd = build(seed, False).flatten(build_bvh=True), build(seed, True).flatten(build_bvh=True)
         sh, sd = R.DeviceScene(fh), R.DeviceScene(fd)

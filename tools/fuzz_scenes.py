@@ -15,6 +15,8 @@ n = int(sys.argv[2]) if len(sys.argv) > 2 else 200
 variant = sys.argv[3] if len(sys.argv) > 3 else "plain"
 bad = refused = lit = overhang = with_meshes = 0
 for seed in range(first, first + n):
+    if (seed - first) % 2000 == 0:
+        print("... seed", seed, flush=True)
     sb, cam, opt, bvh = random_scene(seed, aligned=(variant == "aligned"))
     flat = sb.flatten(build_bvh=bvh)
     sh, pg = np.array(flat.array("prim_shape")), np.array(flat.array("prim_geom"))
