@@ -2894,7 +2894,7 @@ int rt_render_device_noalloc(const rt_scene* scene, const rt_camera* camera, con
   if (options->reference_order || options->pipeline != RT_PIPELINE_STREAM)
     return fail(RT_ERR_INVALID_ARGUMENT, "rt_render_device_noalloc renders with the streamed production pipeline only");
   if (scene->general_csg)
-    return fail(RT_ERR_UNSUPPORTED, "rt_render_device_noalloc: this scene's CSG objects need the general evaluation, which only the allocating entry points run");
+    return fail(RT_ERR_UNSUPPORTED, "rt_render_device_noalloc: this scene takes the reference-order kernels (a CSG object beyond the production kernels' bounds or with an operand that is not a closed surface, or a cone whose cap sticks out of its box), which only the allocating entry points run");
   char* base = (char*)scene->noalloc_scratch;
   if (!base) return fail(RT_ERR_DEVICE, "the static scratch array could not be located on this device (hipGetSymbolAddress)");
   hipStream_t st = (hipStream_t)hip_stream;
