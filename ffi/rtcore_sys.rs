@@ -102,7 +102,7 @@ pub struct rt_options {
     pub max_depth: u32,
     pub shadow_intensity: u32,
     pub reference_order: u32, // 1: visit the BVH exactly as ObjectGroup::intersect_iter does (validation; slow)
-    pub pipeline: u32,        // 0: streamed kernels (production); 1: single kernel
+    pub pipeline: u32,        // 0: production (streamed kernels; the single kernel for scenes without secondary rays); 1: single kernel; 2: streamed always
     pub timing: u32,          // RT_TIMING_ALL (with stats): per-kernel HIP-event times instead of counters; RT_TIMING_ONLY | class bits: those classes only
     pub n_devices: i32,       // rt_render: 0/1 = the current device, n > 1 = tiles over the first n devices, -1 = all
     pub progress: Option<unsafe extern "C" fn(pixels_done: u64, user: *mut c_void)>, // pixels finished since the last call

@@ -196,9 +196,14 @@ typedef struct rt_options {
   uint32_t reference_order;  /* 0: production traversal (near child first, LDS stack).  1: visit the BVH exactly in the
                                 order of ObjectGroup::intersect_iter (group.rs:171-201): validation and counting mode —
                                 same pixels, slower; its node/triangle counts are the reference's algorithmic work */
-  uint32_t pipeline;         /* RT_PIPELINE_STREAM (0, production): rays streamed through trace / shade / combine kernels.
+  uint32_t pipeline;         /* RT_PIPELINE_STREAM (0, production): rays streamed through trace / shade / combine kernels —
+                                except for a scene without triangles none of whose materials reflects or transmits (every ray
+                                tree is a primary ray and its shadow rays; the README scene): that one is rendered by the
+                                single kernel, whose one launch is quicker than the pipeline's six (same pixels; with `timing`
+                                set the pipeline runs all the same).
                                 RT_PIPELINE_SINGLE_KERNEL (1): one kernel holds a pixel's whole recursion (same pixels, bit
                                 for bit; kept for comparison and as the overflow fallback of the streamed pipeline).
+                                RT_PIPELINE_STREAM_ALWAYS (2): the streamed pipeline whatever the scene.
                                 Ignored when reference_order = 1 */
   uint32_t timing;           /* with stats != NULL and the streamed pipeline: launch the production kernels (no counters; the
                                 counter fields of rt_stats stay 0) with a HIP event before and after every launch, and report
@@ -219,6 +224,7 @@ typedef struct rt_options {
 } rt_options;
 #define RT_PIPELINE_STREAM 0u
 #define RT_PIPELINE_SINGLE_KERNEL 1u
+#define RT_PIPELINE_STREAM_ALWAYS 2u
 
 #define RT_MAX_DEPTH 16u
 

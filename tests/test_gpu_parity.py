@@ -621,6 +621,30 @@ def test_streamed_pipeline_equals_single_kernel(name):
     assert st_a["fallback_flags"] == 0
 
 
+def test_scene_without_secondary_rays_takes_one_kernel():
+    """A scene without triangles none of whose materials reflects or transmits (the README scene, BASELINE.json configs[0])
+    is rendered by the single kernel under RT_PIPELINE_STREAM: one launch instead of six.  RT_PIPELINE_STREAM_ALWAYS (2) still
+    runs the streamed kernels on it, `timing` does too; the pixels are the same in every mode.  A scene with one reflective
+    material keeps the streamed pipeline (its shadow rays culled behind the surface are counted, the single kernel's are not)."""
+    rs = Y.load_scene(os.path.join(os.path.dirname(GOLDEN), "..", "scenes", "readme.yml"), width=160, height=120, depth=5, supersampling_level=2)
+    flat, cam, opt = rs.builder.flatten(), rs.camera, rs.options()
+    a, st_a = R.render(flat, cam, opt)
+    always = _single_kernel(opt)
+    always.pipeline = 2
+    b, st_b = R.render(flat, cam, always)
+    c, st_c = R.render(flat, cam, _single_kernel(opt))
+    assert np.array_equal(a, b) and np.array_equal(a, c)
+    assert st_a["rays_shadow_culled"] == 0 and st_a["rays_shadow"] == st_c["rays_shadow"]  # the single kernel ran
+    assert st_b["rays_shadow"] + st_b["rays_shadow_culled"] == st_c["rays_shadow"] and st_b["rays_shadow_culled"] > 0
+    timed = _single_kernel(opt)
+    timed.pipeline, timed.timing = 0, 1
+    d, st_d = R.render(flat, cam, timed)
+    assert np.array_equal(a, d) and st_d["ms_trace_closest"] > 0
+    rs = Y.load_scene(scene_path("images", "chapters/reflections"), width=160, height=120, depth=5, supersampling_level=2)
+    _, st = R.render(rs.builder.flatten(), rs.camera, rs.options())
+    assert st["rays_reflect"] > 0 and st["rays_shadow_culled"] > 0
+
+
 def test_small_batches_and_overflow_fallback(monkeypatch):
     """Many small batches, and a workspace laid out for ONE node record per sample on a scene that needs ~5: the samples
     that do not fit are re-rendered by the fallback kernel, so the pixels do not change; the count of such events comes
