@@ -1026,7 +1026,7 @@ def test_random_scenes_vs_oracle():
         flat = sb.flatten(build_bvh=bvh)
         want, _ = O.render(flat, cam, opt)
         lit += int((want.sum(axis=2) > 0).mean() > 0.3)
-        modes = [{}] + ([{"pipeline": 1}, {"reference_order": 1}] if seed % 8 == 0 else [])
+        modes = [{}, {"pipeline": 2}] + ([{"pipeline": 1}, {"reference_order": 1}] if seed % 8 == 0 else [])
         for kw in modes:
             for k, v in kw.items():
                 setattr(opt, k, v)

@@ -33,12 +33,12 @@ for seed in range(first, first + n):
         with_meshes += 1
         flat = sb2.flatten(build_bvh=bvh)
     lit += int((want.sum(axis=2) > 0).mean() > 0.3)
-    modes = [("streamed", {})] + ([("single", {"pipeline": 1}), ("reference_order", {"reference_order": 1})] if seed % 8 == 0 else [])
+    modes = [("production", {}), ("streamed", {"pipeline": 2})] + ([("single", {"pipeline": 1}), ("reference_order", {"reference_order": 1})] if seed % 8 == 0 else [])
     for name, kw in modes:
         for k, v in kw.items():
             setattr(opt, k, v)
         try:
-            if variant == "meshes" and name != "streamed":  # (a scene consumes its meshes' pose: pose them again)
+            if variant == "meshes" and name != "production":  # (a scene consumes its meshes' pose: pose them again)
                 flat = sb2.flatten(build_bvh=bvh)
             got, _ = R.render(flat, cam, opt, want_stats=False)
         except Exception as e:  # noqa: BLE001
