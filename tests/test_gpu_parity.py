@@ -640,6 +640,21 @@ def test_scene_without_secondary_rays_takes_one_kernel():
     timed.pipeline, timed.timing = 0, 1
     d, st_d = R.render(flat, cam, timed)
     assert np.array_equal(a, d) and st_d["ms_trace_closest"] > 0
+    # its tile parts (rt_render_tiles_device: the multi-GPU path), an image whose sides are no multiples of the tile
+    torch = _torch()
+    rs = Y.load_scene(os.path.join(os.path.dirname(GOLDEN), "..", "scenes", "readme.yml"), width=157, height=83, depth=5, supersampling_level=3)
+    flat, cam, opt = rs.builder.flatten(), rs.camera, rs.options()
+    whole, _ = R.render(flat, cam, opt)
+    sc = R.DeviceScene(flat)
+    n_max = D.tile_count(cam.width, cam.height, 0, 3)
+    bufs = torch.zeros((3, n_max * 64 * 3), dtype=torch.float64, device="cuda")
+    for p in range(3):
+        sc.render_tiles(cam, opt, p, 3, bufs[p].data_ptr())
+    out = torch.empty((cam.height, cam.width, 3), dtype=torch.float64, device="cuda")
+    R.assemble_tiles(cam.width, cam.height, 3, n_max, bufs.data_ptr(), out.data_ptr())
+    torch.cuda.synchronize()
+    assert np.array_equal(out.cpu().numpy(), whole)
+    sc.close()
     rs = Y.load_scene(scene_path("images", "chapters/reflections"), width=160, height=120, depth=5, supersampling_level=2)
     _, st = R.render(rs.builder.flatten(), rs.camera, rs.options())
     assert st["rays_reflect"] > 0 and st["rays_shadow_culled"] > 0
