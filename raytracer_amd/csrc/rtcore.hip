@@ -1681,6 +1681,9 @@ struct TimedLaunch {  // records an event before and after one launch when the s
 #ifndef RT_SHADOW_ON_SIDE_STREAM
 #define RT_SHADOW_ON_SIDE_STREAM 1  // 0: every kernel of the pipeline on the caller's stream, one after the other
 #endif
+#ifndef RT_SHADOW_SIDE_SMALL
+#define RT_SHADOW_SIDE_SMALL (12u << 20)
+#endif
 #ifndef RT_SHADOW_SIDE_MID
 #define RT_SHADOW_SIDE_MID (16u << 20)
 #endif
@@ -1730,9 +1733,21 @@ int run_stream_batch(const rt_scene* sc, const stream::Ws& w, const rt_camera& c
                                                : (b.n_samples >= RT_SHADOW_SIDE_BIG ? 3u : (b.n_samples >= RT_SHADOW_SIDE_MID ? 2u : (uint32_t)RT_SHADOW_SIDE_LEVELS));
   hipStream_t side = use_side ? sc->side_stream : st;
   auto launch_shadow = [&](uint32_t first, uint32_t last, hipStream_t on) {
-    // (a side-stream launch that leaves 1/8, 1/4 or 1/2 of the wavefront slots to the main stream's kernels: the 4K frame 27.1 ->
-    // 27.8 / 28.4 / 31.8 ms: what the overlap buys is the filling of each other's tails, not two kernels side by side)
-    const uint32_t grid = trace_grid;
+    // A side-stream launch of a small batch leaves wavefront slots to the main stream's kernels: half of them below
+    // RT_SHADOW_SIDE_SMALL samples (12 Mi), a quarter up to RT_SHADOW_SIDE_MID.  The persistent shadow wavefronts give up
+    // their slots only when the launch's work has run out, and the main stream's next kernels — the thin deeper levels,
+    // which cannot fill the GPU by themselves — otherwise wait for that (an eighth of the 4K frame: level 1's retrace launch
+    // 0.05 -> 0.66 ms) and then run alone.  800x800: dragons.yml 2.02 -> 1.93 ms, one dragon 2.12 -> 2.08, the CSG lens 7.60 ->
+    // 7.53; 1600x1600 3.50 -> 3.44; an eighth of the 4K frame 4.90 -> 4.85.  Bigger batches keep the full grid: what the
+    // overlap buys there is the filling of each other's tails, not two kernels side by side (7/8, 6/8 of the slots: 1080p
+    // ss 4 8.90 -> 8.94 / 8.98 ms, a quarter of the 4K frame 8.75 -> 8.75 / 8.88; the 4K frame with 7/8, 6/8, 4/8: 27.1 ->
+    // 27.8 / 28.4 / 31.8 ms).  RT_SIDE_GRID_EIGHTHS in the environment fixes the fraction for small batches (development).
+    static const uint32_t side_eighths_env = [] {
+      const char* e = std::getenv("RT_SIDE_GRID_EIGHTHS");
+      return e ? std::min<uint32_t>(8u, (uint32_t)std::strtoul(e, nullptr, 10)) : 0u;
+    }();
+    const uint32_t side_eighths = side_eighths_env ? side_eighths_env : (b.n_samples < RT_SHADOW_SIDE_SMALL ? 4u : 6u);
+    const uint32_t grid = (on != st && b.n_samples < RT_SHADOW_SIDE_MID) ? std::max(8u, trace_grid / 64u * side_eighths * 8u) : trace_grid;
     if (STATS || sc->has_csg)
       hipLaunchKernelGGL((stream::trace_shadow_kernel<STATS, true>), dim3(grid), dim3(64), 0, on, sc->dev, w, first, last, sc->d_stats, sc->d_overflow);
     else
