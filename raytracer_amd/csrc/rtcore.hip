@@ -1685,7 +1685,7 @@ struct TimedLaunch {  // records an event before and after one launch when the s
 #define RT_SHADOW_SIDE_SMALL (12u << 20)
 #endif
 #ifndef RT_SHADOW_SIDE_MID
-#define RT_SHADOW_SIDE_MID (16u << 20)
+#define RT_SHADOW_SIDE_MID (14u << 20)
 #endif
 #ifndef RT_SHADOW_SIDE_BIG
 #define RT_SHADOW_SIDE_BIG (64u << 20)
@@ -1713,7 +1713,9 @@ int run_stream_batch(const rt_scene* sc, const stream::Ws& w, const rt_camera& c
   // kernels; the shadow rays of the other levels are one launch after the last level.  How many levels (k):
   //  * small batches: k = 1 (round 2: an 800x800 frame 3.50 -> 3.23 ms; k = 2 is better for dragons.yml at 800x800 but worse for
   //    the one-dragon room, the CSG lens and refractions.yml, whose levels are all of one size);
-  //  * from RT_SHADOW_SIDE_MID samples (16 Mi): k = 2 (1080p ss 4 9.07 -> 8.89 ms, an eighth of the 4K frame 4.89 -> 4.79);
+  //  * from RT_SHADOW_SIDE_MID samples (14 Mi, so that an eighth of the 4K frame at 16 samples per pixel, 15.8 Mi, is in): k = 2
+  //    (1080p ss 4 9.07 -> 8.89 ms; the eight eighths of the 4K frame, each alone: slowest 5.95 -> 5.55 ms, mean 5.25 -> 5.13 —
+  //    level 1's shadow rays then run beside the thin levels 2 and 3, where a part can hold ONE ray that walks for 0.5 ms);
   //  * from RT_SHADOW_SIDE_BIG samples (64 Mi): k = 3 (the 4K frame 28.2 -> 27.4 ms, half of it 15.4 -> 14.9).
   // Until the end of round 3 big batches used no side stream at all (+1 % then: every kernel of the 4K frame fills the GPU by
   // itself): that was the work hand-out's doing — a launch beside another doubled the traffic on the same eight counters,
