@@ -1731,8 +1731,12 @@ int run_stream_batch(const rt_scene* sc, const stream::Ws& w, const rt_camera& c
     const char* e = std::getenv("RT_SHADOW_SIDE_LEVELS");
     return e ? (uint32_t)std::strtoul(e, nullptr, 10) : 0u;
   }();
+  // (a small batch of a scene whose frames have reported at most one node record per sample — most camera rays hit nothing, the
+  // levels shrink fast: dragons.yml — also takes k = 2: 800x800 1.93 -> 1.72 ms; the one-dragon room, the CSG lens and
+  // refractions.yml, whose every camera ray hits something, report 2 and more and lose 1-6 % with k = 2)
+  const bool sparse = sc->layout_learned && sc->nodes_per_sample == 1;
   const uint32_t side_levels = side_levels_env ? side_levels_env
-                                               : (b.n_samples >= RT_SHADOW_SIDE_BIG ? 3u : (b.n_samples >= RT_SHADOW_SIDE_MID ? 2u : (uint32_t)RT_SHADOW_SIDE_LEVELS));
+                                               : (b.n_samples >= RT_SHADOW_SIDE_BIG ? 3u : ((b.n_samples >= RT_SHADOW_SIDE_MID || sparse) ? 2u : (uint32_t)RT_SHADOW_SIDE_LEVELS));
   hipStream_t side = use_side ? sc->side_stream : st;
   auto launch_shadow = [&](uint32_t first, uint32_t last, hipStream_t on) {
     // A side-stream launch of a small batch leaves wavefront slots to the main stream's kernels: half of them below
